@@ -1,0 +1,214 @@
+// C ABI (include/zeth_gpu.h): argument checking, contexts, resident bases, MSM entry points.
+#include <string.h>
+
+#include <new>
+
+#include "common.cuh"
+
+const GroupOps *ZG_OPS_BN254_G1(), *ZG_OPS_BN254_G2(), *ZG_OPS_BLS377_G1(), *ZG_OPS_BLS377_G2();
+
+const GroupOps* zg_group_ops(int curve, int group) {
+  if (curve == ZG_CURVE_ALT_BN128) return group == ZG_GROUP_G1 ? ZG_OPS_BN254_G1() : group == ZG_GROUP_G2 ? ZG_OPS_BN254_G2() : nullptr;
+  if (curve == ZG_CURVE_BLS12_377) return group == ZG_GROUP_G1 ? ZG_OPS_BLS377_G1() : group == ZG_GROUP_G2 ? ZG_OPS_BLS377_G2() : nullptr;
+  return nullptr;
+}
+
+extern "C" {
+
+const char* zg_strerror(int s) {
+  switch (s) {
+    case ZG_OK: return "ok";
+    case ZG_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case ZG_ERR_LENGTH: return "length error";
+    case ZG_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case ZG_ERR_HIP: return "HIP runtime error";
+    case ZG_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case ZG_ERR_UNSUPPORTED: return "unsupported size or configuration";
+    default: return "unknown status";
+  }
+}
+
+int zg_sizes(int curve, size_t* fr, size_t* fq, size_t* g1, size_t* g2) {
+  const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
+  const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
+  if (!o1 || !o2) return ZG_ERR_INVALID_ARGUMENT;
+  if (fr) *fr = 32;
+  if (fq) *fq = o1->fq_limbs * 4;
+  if (g1) *g1 = o1->affine_bytes;
+  if (g2) *g2 = o2->affine_bytes;
+  return ZG_OK;
+}
+
+int zg_ctx_create(int device, zg_ctx** out) {
+  if (!out) return ZG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZG_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(device));
+  zg_ctx* c = new (std::nothrow) zg_ctx();
+  if (!c) return ZG_ERR_OUT_OF_MEMORY;
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return ZG_ERR_HIP;
+  }
+  *out = c;
+  return ZG_OK;
+}
+
+void zg_ctx_destroy(zg_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  if (c->ws) hipFree(c->ws);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int zg_ctx_set_profiling(zg_ctx* c, int enabled) {
+  if (!c) return ZG_ERR_INVALID_ARGUMENT;
+  c->profiling = enabled != 0;
+  return ZG_OK;
+}
+
+int zg_ctx_last_timings(zg_ctx* c, const char** names, float* ms, int max_entries, int* n_entries) {
+  if (!c || !n_entries) return ZG_ERR_INVALID_ARGUMENT;
+  int n = (int)c->last_ms.size();
+  if (n > max_entries) n = max_entries;
+  for (int i = 0; i < n; i++) {
+    if (names) names[i] = c->last_names[i];
+    if (ms) ms[i] = c->last_ms[i];
+  }
+  *n_entries = n;
+  return ZG_OK;
+}
+
+static int bases_alloc(zg_ctx* ctx, int curve, int group, size_t n, zg_bases** out) {
+  if (!ctx || !out) return ZG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ops) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  zg_bases* b = new (std::nothrow) zg_bases();
+  if (!b) return ZG_ERR_OUT_OF_MEMORY;
+  b->ctx = ctx;
+  b->curve = curve;
+  b->group = group;
+  b->n = n;
+  b->ops = ops;
+  b->d_pts = nullptr;
+  if (n) {
+    hipError_t e = hipMalloc(&b->d_pts, n * ops->affine_bytes);
+    if (e != hipSuccess) {
+      delete b;
+      return e == hipErrorOutOfMemory ? ZG_ERR_OUT_OF_MEMORY : ZG_ERR_HIP;
+    }
+  }
+  *out = b;
+  return ZG_OK;
+}
+
+int zg_bases_create(zg_ctx* ctx, int curve, int group, const void* points, size_t n, int form, int mem,
+                    zg_bases** out) {
+  if ((n && !points) || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT) || (mem != ZG_MEM_HOST && mem != ZG_MEM_DEVICE))
+    return ZG_ERR_INVALID_ARGUMENT;
+  zg_bases* b = nullptr;
+  ZG_TRY(bases_alloc(ctx, curve, group, n, &b));
+  int s = ZG_OK;
+  if (n) {
+    hipError_t e = hipMemcpyAsync(b->d_pts, points, n * b->ops->affine_bytes,
+                                  mem == ZG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) s = ZG_ERR_HIP;
+    if (s == ZG_OK && form == ZG_FORM_PLAIN) s = b->ops->to_mont(ctx, b->d_pts, n);
+    if (s == ZG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = ZG_ERR_HIP;
+  }
+  if (s != ZG_OK) {
+    zg_bases_free(b);
+    return s;
+  }
+  *out = b;
+  return ZG_OK;
+}
+
+int zg_bases_generate(zg_ctx* ctx, int curve, int group, size_t n, const void* t0, const void* d, zg_bases** out) {
+  if (!t0 || !d) return ZG_ERR_INVALID_ARGUMENT;
+  zg_bases* b = nullptr;
+  ZG_TRY(bases_alloc(ctx, curve, group, n, &b));
+  int s = b->ops->generate(ctx, b->d_pts, n, (const uint32_t*)t0, (const uint32_t*)d);
+  if (s != ZG_OK) {
+    zg_bases_free(b);
+    return s;
+  }
+  *out = b;
+  return ZG_OK;
+}
+
+int zg_bases_count(const zg_bases* b, size_t* n) {
+  if (!b || !n) return ZG_ERR_INVALID_ARGUMENT;
+  *n = b->n;
+  return ZG_OK;
+}
+
+int zg_bases_read(zg_bases* b, size_t first, size_t count, int form, void* out) {
+  if (!b || (count && !out) || first > b->n || count > b->n - first) return ZG_ERR_INVALID_ARGUMENT;
+  if (!count) return ZG_OK;
+  ZG_HIP(hipSetDevice(b->ctx->device));
+  ZG_HIP(hipMemcpy(out, (const char*)b->d_pts + first * b->ops->affine_bytes, count * b->ops->affine_bytes,
+                   hipMemcpyDeviceToHost));
+  if (form == ZG_FORM_PLAIN) b->ops->host_convert(out, count, 0);
+  return ZG_OK;
+}
+
+void zg_bases_free(zg_bases* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  if (b->d_pts) hipFree(b->d_pts);
+  delete b;
+}
+
+int zg_msm_ex(zg_bases* b, size_t first, const void* scalars, size_t n, int scalar_form, int scalars_mem,
+              int out_form, void* out_affine, int window_bits) {
+  if (!b || !out_affine || (n && !scalars)) return ZG_ERR_INVALID_ARGUMENT;
+  if (first > b->n || n > b->n - first) return ZG_ERR_INVALID_ARGUMENT;  // multi_exp.tcc:28-31
+  if ((scalar_form != ZG_FORM_PLAIN && scalar_form != ZG_FORM_MONT) || (out_form != ZG_FORM_PLAIN && out_form != ZG_FORM_MONT))
+    return ZG_ERR_INVALID_ARGUMENT;
+  if (window_bits != 0 && (window_bits < 2 || window_bits > 16)) return ZG_ERR_INVALID_ARGUMENT;
+  zg_ctx* ctx = b->ctx;
+  ZG_HIP(hipSetDevice(ctx->device));
+  const uint32_t* d_scalars = (const uint32_t*)scalars;
+  void* staged = nullptr;
+  if (n && scalars_mem == ZG_MEM_HOST) {
+    ZG_HIP(hipMalloc(&staged, n * 32));
+    hipError_t e = hipMemcpyAsync(staged, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+      hipFree(staged);
+      return ZG_ERR_HIP;
+    }
+    d_scalars = (const uint32_t*)staged;
+  } else if (scalars_mem != ZG_MEM_DEVICE && scalars_mem != ZG_MEM_HOST) {
+    return ZG_ERR_INVALID_ARGUMENT;
+  }
+  int s = b->ops->msm(ctx, (const char*)b->d_pts + first * b->ops->affine_bytes, d_scalars, n,
+                      scalar_form == ZG_FORM_MONT, window_bits, out_form, out_affine);
+  if (staged) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(staged);
+  }
+  return s;
+}
+
+int zg_msm(zg_bases* b, size_t first, const void* scalars, size_t n, int scalar_form, int scalars_mem, int out_form,
+           void* out_affine) {
+  return zg_msm_ex(b, first, scalars, n, scalar_form, scalars_mem, out_form, out_affine, 0);
+}
+
+int zg_host_group_op(int curve, int group, int op, const void* a, const void* b, int form, void* out) {
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ops || !a || !b || !out) return ZG_ERR_INVALID_ARGUMENT;
+  return ops->host_op(op, a, b, form, out);
+}
+
+}  // extern "C"

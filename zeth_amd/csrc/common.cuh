@@ -1,0 +1,114 @@
+// Context, device workspace and error plumbing shared by the library's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/zeth_gpu.h"
+
+#define ZG_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      fprintf(stderr, "zeth_gpu: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return _e == hipErrorOutOfMemory ? ZG_ERR_OUT_OF_MEMORY : ZG_ERR_HIP;                            \
+    }                                                                                                  \
+  } while (0)
+
+#define ZG_TRY(expr)          \
+  do {                        \
+    int _s = (expr);          \
+    if (_s != ZG_OK) return _s; \
+  } while (0)
+
+struct zg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // grow-only workspace, bump-allocated per call
+  char* ws = nullptr;
+  size_t ws_cap = 0, ws_used = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<const char*> ev_names;
+  size_t ev_used = 0;
+  std::vector<const char*> last_names;
+  std::vector<float> last_ms;
+
+  int ws_reserve(size_t bytes) {
+    ws_used = 0;
+    if (bytes <= ws_cap) return ZG_OK;
+    ZG_HIP(hipStreamSynchronize(stream));
+    if (ws) ZG_HIP(hipFree(ws));
+    ws = nullptr;
+    ws_cap = 0;
+    size_t want = bytes + (bytes >> 3) + (1u << 20);
+    ZG_HIP(hipMalloc((void**)&ws, want));
+    ws_cap = want;
+    return ZG_OK;
+  }
+  template <class T>
+  T* ws_take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (ws_used + bytes > ws_cap) return nullptr;
+    T* p = reinterpret_cast<T*>(ws + ws_used);
+    ws_used += bytes;
+    return p;
+  }
+  static size_t ws_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+  void prof_begin() {
+    ev_used = 0;
+    ev_names.clear();
+  }
+  // marks the START of phase `name` (and the end of the previous one)
+  void mark(const char* name) {
+    if (!profiling) return;
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      ev_pool.push_back(e);
+    }
+    hipEventRecord(ev_pool[ev_used++], stream);
+    ev_names.push_back(name);
+  }
+  // call after the stream has been synchronised
+  void prof_end() {
+    if (!profiling) return;
+    last_names.clear();
+    last_ms.clear();
+    for (size_t i = 0; i + 1 < ev_used; i++) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]);
+      last_names.push_back(ev_names[i]);
+      last_ms.push_back(ms);
+    }
+  }
+};
+
+struct GroupOps {
+  size_t affine_bytes;
+  size_t fq_limbs;  // limbs per coordinate-field base element
+  int coords;       // field elements per affine point (2 for G1, 4 for G2)
+  // d_pts: device affine points (Montgomery).  d_scalars: device Fr elements.
+  int (*msm)(zg_ctx*, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
+             int out_form, void* out_affine_host);
+  int (*to_mont)(zg_ctx*, void* d_pts, size_t n);  // plain -> Montgomery in place
+  int (*generate)(zg_ctx*, void* d_pts, size_t n, const uint32_t* t0, const uint32_t* d);
+  int (*host_op)(int op, const void* a, const void* b, int form, void* out);
+  // host-side conversion of `n` affine points between forms, in place (mont <-> plain)
+  void (*host_convert)(void* pts, size_t n, int to_mont);
+};
+
+const GroupOps* zg_group_ops(int curve, int group);
+
+struct zg_bases {
+  zg_ctx* ctx;
+  int curve, group;
+  size_t n;
+  void* d_pts;
+  const GroupOps* ops;
+};

@@ -1,0 +1,343 @@
+// Pippenger / bucket multi-scalar multiplication for gfx950.
+//
+// Replaces libff::multi_exp / multi_exp_with_mixed_addition / multi_exp_filter_one_zero with method
+// BDLO12 (absent submodule; Zeth's call sites libzeth/core/multi_exp.tcc:20-22,32-34 and, inside the
+// libsnark prover, the A/B/H/L query evaluations -- SURVEY.md section 3.1 step 5c).  The result is the group
+// element sum_i f_i * g_i, returned as its unique affine point, so it is bit-identical to any correct
+// evaluation order.
+//
+// Pipeline (all on the device, one HIP stream):
+//   k_digits   scalar -> W signed c-bit digits (int16), via s + sum_w 2^(c-1) 2^(wc) then per-window re-centre
+//   k_hist     per (chunk, window) LDS histogram of |digit| (128 KB of LDS at c = 16) -> global counts
+//   k_scan     per window exclusive scan -> bucket offsets, work-unit offsets (a unit = <= L entries of one bucket)
+//   k_scatter  counting-sort scatter of (point index | sign) through LDS cursors
+//   k_units    unit table
+//   k_accum    one lane per unit: gather affine bases (64-byte AoS records), XYZZ mixed add      <- dominant
+//   k_reduce1  per (window, bucket segment): combine units, running-sum, weight by segment start
+//   k_reduce2  per window tree reduction -> W window sums
+// Host tail: Horner over the W window sums (c doublings each) and normalisation to affine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "curve.cuh"
+
+namespace zg {
+
+static constexpr int MSM_MAX_C = 16;
+static constexpr int MSM_MAX_W = 48;
+
+struct AddConst {
+  uint32_t k[9];
+};
+
+struct UnitDesc {
+  uint64_t start;   // absolute index into sorted[]
+  uint32_t len;     // entries in this unit
+  uint32_t bucket;  // w * nb + b
+};
+
+struct MsmPlan {
+  size_t n;
+  int c, W;
+  uint32_t nb;     // buckets per window = 2^(c-1); bucket b has weight b + 1
+  uint32_t L;      // max entries per work unit
+  uint32_t cap;    // unit slots per window
+  uint32_t nchunk; // histogram/scatter chunks per window
+  uint32_t T;      // bucket segments per window (reduce1 lanes per window)
+  uint32_t k;      // buckets per segment
+  AddConst K;
+};
+
+inline int ilog2_floor(size_t n) {
+  int l = 0;
+  while ((n >> (l + 1)) != 0) l++;
+  return l;
+}
+
+inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
+  MsmPlan p{};
+  p.n = n;
+  int c = ilog2_floor(n ? n : 1) - 4;
+  if (c < 6) c = 6;
+  if (c > MSM_MAX_C) c = MSM_MAX_C;
+  if (force_c) c = force_c;
+  p.c = c;
+  // need W*c >= scalar_bits + 2 so that s + K never overflows W windows
+  p.W = (scalar_bits + 2 + c - 1) / c;
+  p.nb = 1u << (c - 1);
+  size_t avg = n / p.nb;
+  size_t L = 2 * avg;
+  if (L < 32) L = 32;
+  p.L = (uint32_t)L;
+  p.cap = p.nb + (uint32_t)(n / L) + 1;
+  uint32_t nchunk = (uint32_t)((n + (1u << 16) - 1) >> 16);  // >= 64K entries per chunk
+  if (nchunk < 1) nchunk = 1;
+  uint32_t maxchunk = 512u / (uint32_t)p.W;  // about two blocks per CU in total
+  if (maxchunk < 1) maxchunk = 1;
+  if (nchunk > maxchunk) nchunk = maxchunk;
+  p.nchunk = nchunk;
+  p.T = p.nb < 1024 ? p.nb : 1024;
+  p.k = p.nb / p.T;
+  for (int i = 0; i < 9; i++) p.K.k[i] = 0;
+  for (int w = 0; w < p.W; w++) {
+    int bit = w * c + (c - 1);
+    p.K.k[bit / 32] |= 1u << (bit % 32);
+  }
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar recoding
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
+                                                 int W, AddConst K, int16_t* __restrict__ dig) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s;
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  uint4 lo = sp[0], hi = sp[1];
+  s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+  s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+  if (mont) s = Fr::from_mont(s);
+  uint32_t t[9];
+  uint64_t cy = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    cy += (uint64_t)s.v[j] + K.k[j];
+    t[j] = (uint32_t)cy;
+    cy >>= 32;
+  }
+  t[8] = (uint32_t)cy + K.k[8];
+  const uint32_t mask = (1u << c) - 1u;
+  const int half = 1 << (c - 1);
+  uint64_t buf = 0;
+  int have = 0, w = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    buf |= (uint64_t)t[j] << have;
+    have += 32;
+    while (have >= c && w < W) {
+      int d = (int)(buf & mask) - half;
+      dig[(size_t)w * n + i] = (int16_t)d;
+      buf >>= c;
+      have -= c;
+      w++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// counting sort by |digit| per window
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(1024) k_hist(const int16_t* __restrict__ dig, size_t n, uint32_t nb, uint32_t nchunk,
+                                                uint32_t* __restrict__ cnt) {
+  extern __shared__ uint32_t lh[];
+  const uint32_t w = blockIdx.y, chunk = blockIdx.x;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  size_t per = (n + nchunk - 1) / nchunk;
+  size_t lo = (size_t)chunk * per, hi = lo + per;
+  if (hi > n) hi = n;
+  const int16_t* d = dig + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int v = d[i];
+    if (v != 0) atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    uint32_t v = lh[b];
+    if (v) atomicAdd(&cnt[(size_t)w * nb + b], v);
+  }
+}
+
+// one block (1024 lanes) per window: exclusive scans of bucket counts and of unit counts
+static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ cnt, size_t n, uint32_t nb, uint32_t L,
+                                                uint32_t cap, uint32_t* __restrict__ cursor /* absolute positions */,
+                                                uint32_t* __restrict__ boff /* bucket start, absolute */,
+                                                uint32_t* __restrict__ ufirst /* first unit, absolute */,
+                                                uint32_t* __restrict__ wunits) {
+  __shared__ uint32_t sa[1024], sb[1024];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  const uint32_t per = (nb + 1023) / 1024;
+  const uint32_t b0 = tid * per;
+  uint32_t ca = 0, cb = 0;
+  for (uint32_t j = 0; j < per; j++) {
+    uint32_t b = b0 + j;
+    if (b < nb) {
+      uint32_t v = cnt[(size_t)w * nb + b];
+      ca += v;
+      cb += (v + L - 1) / L;
+    }
+  }
+  sa[tid] = ca;
+  sb[tid] = cb;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t xa = 0, xb = 0;
+    if (tid >= off) {
+      xa = sa[tid - off];
+      xb = sb[tid - off];
+    }
+    __syncthreads();
+    sa[tid] += xa;
+    sb[tid] += xb;
+    __syncthreads();
+  }
+  uint32_t ea = sa[tid] - ca, eb = sb[tid] - cb;  // exclusive prefixes
+  if (tid == 1023) wunits[w] = sb[1023];
+  const uint32_t abase = (uint32_t)((size_t)w * n);
+  const uint32_t ubase = w * cap;
+  for (uint32_t j = 0; j < per; j++) {
+    uint32_t b = b0 + j;
+    if (b < nb) {
+      uint32_t v = cnt[(size_t)w * nb + b];
+      cursor[(size_t)w * nb + b] = abase + ea;
+      boff[(size_t)w * nb + b] = abase + ea;
+      ufirst[(size_t)w * nb + b] = ubase + eb;
+      ea += v;
+      eb += (v + L - 1) / L;
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restrict__ dig, size_t n, uint32_t nb,
+                                                   uint32_t nchunk, uint32_t* __restrict__ cursor,
+                                                   uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lh[];
+  const uint32_t w = blockIdx.y, chunk = blockIdx.x;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  size_t per = (n + nchunk - 1) / nchunk;
+  size_t lo = (size_t)chunk * per, hi = lo + per;
+  if (hi > n) hi = n;
+  const int16_t* d = dig + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int v = d[i];
+    if (v != 0) atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+  }
+  __syncthreads();
+  // claim this block's slice of every bucket it touches; lh[b] becomes the block-private write cursor
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    uint32_t v = lh[b];
+    if (v) lh[b] = atomicAdd(&cursor[(size_t)w * nb + b], v);
+  }
+  __syncthreads();
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int v = d[i];
+    if (v != 0) {
+      uint32_t pos = atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+      sorted[pos] = (uint32_t)i | (v < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
+                                                const uint32_t* __restrict__ ufirst, uint32_t nb, uint32_t W, uint32_t L,
+                                                UnitDesc* __restrict__ units) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nb * W) return;
+  uint32_t v = cnt[g];
+  uint32_t u = ufirst[g];
+  uint64_t start = boff[g];
+  while (v) {
+    uint32_t len = v < L ? v : L;
+    units[u] = UnitDesc{start, len, (uint32_t)g};
+    u++;
+    start += len;
+    v -= len;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket accumulation (dominant kernel)
+// ---------------------------------------------------------------------------------------------
+template <class F>
+ZG_HD Affine<F> load_affine(const Affine<F>* __restrict__ bases, size_t idx) {
+  constexpr int NW = sizeof(Affine<F>) / 16;
+  union {
+    uint4 q[NW];
+    Affine<F> p;
+  } u;
+  const uint4* src = reinterpret_cast<const uint4*>(bases + idx);
+#pragma unroll
+  for (int i = 0; i < NW; i++) u.q[i] = src[i];
+  return u.p;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
+                                                uint32_t cap, const uint32_t* __restrict__ sorted,
+                                                const Affine<F>* __restrict__ bases, XYZZ<F>* __restrict__ part) {
+  const uint32_t w = blockIdx.y;
+  const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ul >= wunits[w]) return;
+  const size_t u = (size_t)w * cap + ul;
+  const UnitDesc d = units[u];
+  const uint32_t* __restrict__ ent = sorted + d.start;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  uint32_t e = ent[0];
+  Affine<F> p = load_affine(bases, e & 0x7FFFFFFFu);
+  for (uint32_t t = 0; t < d.len; t++) {
+    // prefetch the next entry's base while this one is being added
+    uint32_t en = (t + 1 < d.len) ? ent[t + 1] : e;
+    Affine<F> pn = load_affine(bases, en & 0x7FFFFFFFu);
+    p.y = F::cneg(p.y, (e >> 31) != 0);
+    xyzz_madd(acc, p);
+    e = en;
+    p = pn;
+  }
+  part[u] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket reduction
+// ---------------------------------------------------------------------------------------------
+// lane (w, j): buckets [j*k, (j+1)*k) of window w; seg[w*T + j] = sum_b (b + 1) * B_b over the segment
+template <class F>
+__global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
+                                                  const XYZZ<F>* __restrict__ part, uint32_t nb, uint32_t T, uint32_t k,
+                                                  uint32_t L, uint32_t W, XYZZ<F>* __restrict__ seg) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= T * W) return;
+  uint32_t w = g / T, j = g % T;
+  XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
+  for (int bb = (int)k - 1; bb >= 0; bb--) {
+    size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
+    uint32_t v = cnt[gid];
+    uint32_t nu = (v + L - 1) / L;
+    uint32_t u0 = ufirst[gid];
+    for (uint32_t s = 0; s < nu; s++) xyzz_add(run, part[u0 + s]);
+    xyzz_add(tot, run);
+  }
+  // tot = sum (b - j*k + 1) B_b ; add (j*k) * run
+  uint32_t start = j * k;
+  if (start != 0 && !run.is_inf()) {
+    XYZZ<F> r = XYZZ<F>::inf();
+    for (int b = 15; b >= 0; b--) {
+      r = xyzz_dbl(r);
+      if ((start >> b) & 1u) xyzz_add(r, run);
+    }
+    xyzz_add(tot, r);
+  }
+  seg[g] = tot;
+}
+
+// one block of T lanes per window: tree-sum seg[w*T .. w*T+T) into seg[w*T]
+template <class F>
+__global__ void __launch_bounds__(1024) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
+  XYZZ<F>* s = seg + (size_t)blockIdx.x * T;
+  for (uint32_t h = T >> 1; h >= 1; h >>= 1) {
+    if (threadIdx.x < h) {
+      XYZZ<F> a = s[threadIdx.x];
+      XYZZ<F> b = s[threadIdx.x + h];
+      xyzz_add(a, b);
+      s[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace zg

@@ -1,0 +1,297 @@
+// Host driver for the MSM pipeline plus base-point set-up kernels, generic over the group.
+// One translation unit per (curve, group) instantiates this through ZG_DEFINE_GROUP_OPS.
+#pragma once
+#include <string.h>
+
+#include "common.cuh"
+#include "msm.cuh"
+
+namespace zg {
+
+template <class F>
+struct BaseField {
+  using type = F;
+};
+template <class B, int K>
+struct BaseField<Fp2<B, K>> {
+  using type = B;
+};
+
+// ---------------------------------------------------------------------------------------------
+// set-up kernels
+// ---------------------------------------------------------------------------------------------
+template <class B>
+__global__ void __launch_bounds__(256) k_to_mont(B* __restrict__ elems, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  elems[i] = B::to_mont(elems[i]);
+}
+
+static constexpr uint32_t GEN_CHUNK = 64;
+
+// lane j: points [j*64, j*64+64): start (t0 + j*64*d) * G by double-and-add, then repeated + D
+template <class F, class Fr>
+__global__ void __launch_bounds__(64) k_gen_points(Affine<F> G, Affine<F> D, Fr t0m, Fr dm, size_t n,
+                                                    XYZZ<F>* __restrict__ tmp) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t lo = j * GEN_CHUNK;
+  if (lo >= n) return;
+  size_t hi = lo + GEN_CHUNK;
+  if (hi > n) hi = n;
+  Fr idx = Fr::zero();
+  idx.v[0] = (uint32_t)lo;
+  idx.v[1] = (uint32_t)((uint64_t)lo >> 32);
+  Fr s = Fr::from_mont(Fr::add(t0m, Fr::mul(Fr::to_mont(idx), dm)));
+  uint32_t k[Fr::N];
+#pragma unroll
+  for (int i = 0; i < Fr::N; i++) k[i] = s.v[i];
+  XYZZ<F> acc = xyzz_mul_limbs(XYZZ<F>::from_affine(G), k, Fr::N);
+  for (size_t i = lo; i < hi; i++) {
+    tmp[i] = acc;
+    xyzz_madd(acc, D);
+  }
+}
+
+// lane j normalises its 64 points with one shared inversion (Montgomery's trick on zzz)
+template <class F>
+__global__ void __launch_bounds__(64) k_normalize(const XYZZ<F>* __restrict__ tmp, F* __restrict__ pref, size_t n,
+                                                   Affine<F>* __restrict__ out) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t lo = j * GEN_CHUNK;
+  if (lo >= n) return;
+  size_t hi = lo + GEN_CHUNK;
+  if (hi > n) hi = n;
+  F prod = F::one();
+  for (size_t i = lo; i < hi; i++) {
+    F z = tmp[i].zzz;
+    if (z.is_zero()) z = F::one();
+    pref[i] = prod;
+    prod = F::mul(prod, z);
+  }
+  F inv = F::inv(prod);
+  for (size_t i = hi; i-- > lo;) {
+    XYZZ<F> p = tmp[i];
+    bool isinf = p.zzz.is_zero();
+    F z = isinf ? F::one() : p.zzz;
+    F izzz = F::mul(inv, pref[i]);
+    inv = F::mul(inv, z);
+    F iz = F::mul(p.zz, izzz);
+    F izz = F::sqr(iz);
+    Affine<F> a{F::mul(p.x, izz), F::mul(p.y, izzz)};
+    out[i] = isinf ? Affine<F>::inf() : a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers (the O(1) tail of an MSM / proof assembly)
+// ---------------------------------------------------------------------------------------------
+template <class F>
+inline void host_affine_convert(Affine<F>* pts, size_t n, int to_mont) {
+  using B = typename BaseField<F>::type;
+  B* e = reinterpret_cast<B*>(pts);
+  size_t cnt = n * (sizeof(Affine<F>) / sizeof(B));
+  for (size_t i = 0; i < cnt; i++) e[i] = to_mont ? B::to_mont(e[i]) : B::from_mont(e[i]);
+}
+
+template <class F>
+inline XYZZ<F> host_horner(const XYZZ<F>* win, int W, int c) {
+  XYZZ<F> acc = win[W - 1];
+  for (int w = W - 2; w >= 0; w--) {
+    for (int i = 0; i < c; i++) acc = xyzz_dbl(acc);
+    xyzz_add(acc, win[w]);
+  }
+  return acc;
+}
+
+template <class F, class Fr>
+int host_group_op(int op, const void* a, const void* b, int form, void* out) {
+  Affine<F> pa;
+  memcpy(&pa, a, sizeof(pa));
+  if (form == ZG_FORM_PLAIN) host_affine_convert(&pa, 1, 1);
+  XYZZ<F> r;
+  if (op == 0) {
+    Affine<F> pb;
+    memcpy(&pb, b, sizeof(pb));
+    if (form == ZG_FORM_PLAIN) host_affine_convert(&pb, 1, 1);
+    r = XYZZ<F>::from_affine(pa);
+    xyzz_madd(r, pb);
+  } else if (op == 1) {
+    uint32_t k[Fr::N];
+    memcpy(k, b, sizeof(k));
+    r = xyzz_mul_limbs(XYZZ<F>::from_affine(pa), k, Fr::N);
+  } else {
+    return ZG_ERR_INVALID_ARGUMENT;
+  }
+  Affine<F> o = xyzz_to_affine(r);
+  if (form == ZG_FORM_PLAIN) host_affine_convert(&o, 1, 0);
+  memcpy(out, &o, sizeof(o));
+  return ZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MSM driver
+// ---------------------------------------------------------------------------------------------
+// Runs the device pipeline and leaves the W window sums in host memory `win` (size >= plan.W).
+template <class F, class Fr>
+int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars, size_t n, int scalars_mont,
+               int force_c, MsmPlan& plan, std::vector<XYZZ<F>>& win) {
+  plan = msm_make_plan(n, Fr::Params::BITS, force_c);
+  const MsmPlan& p = plan;
+  if ((uint64_t)p.W * (uint64_t)n >= (1ull << 32)) return ZG_ERR_UNSUPPORTED;
+  const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
+  size_t need = zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
+                zg_ctx::ws_round(p.W * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
+                zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
+  ZG_TRY(ctx->ws_reserve(need));
+  int16_t* dig = ctx->ws_take<int16_t>(WN);
+  uint32_t* sorted = ctx->ws_take<uint32_t>(WN);
+  uint32_t* cnt = ctx->ws_take<uint32_t>(WB);
+  uint32_t* cursor = ctx->ws_take<uint32_t>(WB);
+  uint32_t* boff = ctx->ws_take<uint32_t>(WB);
+  uint32_t* ufirst = ctx->ws_take<uint32_t>(WB);
+  uint32_t* wunits = ctx->ws_take<uint32_t>(p.W);
+  UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
+  XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
+  XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)p.W * p.T);
+  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !wunits || !units || !part || !seg)
+    return ZG_ERR_OUT_OF_MEMORY;
+
+  hipStream_t st = ctx->stream;
+  const size_t lds = (size_t)p.nb * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    ZG_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
+    ZG_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
+    attr_done = true;
+  }
+  ctx->prof_begin();
+  ctx->mark("digits");
+  ZG_HIP(hipMemsetAsync(cnt, 0, WB * 4, st));
+  hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
+                     p.c, p.W, p.K, dig);
+  ctx->mark("hist");
+  hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
+  ctx->mark("scan");
+  hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits);
+  ctx->mark("scatter");
+  hipLaunchKernelGGL(k_scatter, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cursor, sorted);
+  ctx->mark("units");
+  hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, p.nb,
+                     (uint32_t)p.W, p.L, units);
+  ctx->mark("accum");
+  hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, p.cap, sorted,
+                     d_bases, part);
+  ctx->mark("reduce1");
+  hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
+                     p.k, p.L, (uint32_t)p.W, seg);
+  ctx->mark("reduce2");
+  hipLaunchKernelGGL((k_reduce2<F>), dim3(p.W), dim3(p.T), 0, st, seg, p.T);
+  ctx->mark("end");
+  ZG_HIP(hipGetLastError());
+  win.resize(p.W);
+  // gather the W window sums (strided by T) with one 2D copy
+  ZG_HIP(hipMemcpy2DAsync(win.data(), sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), p.W,
+                          hipMemcpyDeviceToHost, st));
+  ZG_HIP(hipStreamSynchronize(st));
+  ctx->prof_end();
+  return ZG_OK;
+}
+
+template <class F, class Fr>
+int msm_run(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
+            int out_form, void* out_affine_host) {
+  Affine<F> res = Affine<F>::inf();
+  if (n > 0) {
+    MsmPlan plan;
+    std::vector<XYZZ<F>> win;
+    ZG_TRY((msm_device<F, Fr>(ctx, reinterpret_cast<const Affine<F>*>(d_pts), d_scalars, n, scalars_mont, force_c,
+                              plan, win)));
+    res = xyzz_to_affine(host_horner(win.data(), plan.W, plan.c));
+  }
+  if (out_form == ZG_FORM_PLAIN) host_affine_convert(&res, 1, 0);
+  memcpy(out_affine_host, &res, sizeof(res));
+  return ZG_OK;
+}
+
+template <class F>
+int bases_to_mont(zg_ctx* ctx, void* d_pts, size_t n) {
+  using B = typename BaseField<F>::type;
+  size_t cnt = n * (sizeof(Affine<F>) / sizeof(B));
+  if (cnt == 0) return ZG_OK;
+  hipLaunchKernelGGL((k_to_mont<B>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<B*>(d_pts), cnt);
+  ZG_HIP(hipGetLastError());
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  return ZG_OK;
+}
+
+template <class F, class Fr, class Gen>
+int bases_generate(zg_ctx* ctx, void* d_pts, size_t n, const uint32_t* t0, const uint32_t* d) {
+  if (n == 0) return ZG_OK;
+  Fr t0p, dp;
+  memcpy(&t0p, t0, sizeof(Fr));
+  memcpy(&dp, d, sizeof(Fr));
+  Affine<F> G = Gen::gen();
+  uint32_t k[Fr::N];
+  memcpy(k, d, sizeof(k));
+  Affine<F> D = xyzz_to_affine(xyzz_mul_limbs(XYZZ<F>::from_affine(G), k, Fr::N));
+  size_t need = zg_ctx::ws_round(n * sizeof(XYZZ<F>)) + zg_ctx::ws_round(n * sizeof(F));
+  ZG_TRY(ctx->ws_reserve(need));
+  XYZZ<F>* tmp = ctx->ws_take<XYZZ<F>>(n);
+  F* pref = ctx->ws_take<F>(n);
+  if (!tmp || !pref) return ZG_ERR_OUT_OF_MEMORY;
+  size_t lanes = (n + GEN_CHUNK - 1) / GEN_CHUNK;
+  unsigned blocks = (unsigned)((lanes + 63) / 64);
+  hipLaunchKernelGGL((k_gen_points<F, Fr>), dim3(blocks), dim3(64), 0, ctx->stream, G, D, Fr::to_mont(t0p),
+                     Fr::to_mont(dp), n, tmp);
+  hipLaunchKernelGGL((k_normalize<F>), dim3(blocks), dim3(64), 0, ctx->stream, tmp, pref, n,
+                     reinterpret_cast<Affine<F>*>(d_pts));
+  ZG_HIP(hipGetLastError());
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  return ZG_OK;
+}
+
+template <class F>
+void host_convert_thunk(void* pts, size_t n, int to_mont) {
+  host_affine_convert(reinterpret_cast<Affine<F>*>(pts), n, to_mont);
+}
+
+template <class Fq, class GP>
+struct G1Gen {
+  static Affine<Fq> gen() {
+    Affine<Fq> g;
+    for (int i = 0; i < Fq::N; i++) {
+      g.x.v[i] = GP::GX_MONT[i];
+      g.y.v[i] = GP::GY_MONT[i];
+    }
+    return g;
+  }
+};
+template <class Fq2T, class GP>
+struct G2Gen {
+  static Affine<Fq2T> gen() {
+    Affine<Fq2T> g;
+    for (int i = 0; i < Fq2T::Base::N; i++) {
+      g.x.c0.v[i] = GP::GX_C0_MONT[i];
+      g.x.c1.v[i] = GP::GX_C1_MONT[i];
+      g.y.c0.v[i] = GP::GY_C0_MONT[i];
+      g.y.c1.v[i] = GP::GY_C1_MONT[i];
+    }
+    return g;
+  }
+};
+
+}  // namespace zg
+
+#define ZG_DEFINE_GROUP_OPS(NAME, F, FR, GEN)                                                     \
+  const GroupOps* NAME() {                                                                        \
+    static GroupOps ops = {sizeof(zg::Affine<F>),                                            \
+                                (size_t)zg::BaseField<F>::type::N,                                \
+                                (int)(sizeof(zg::Affine<F>) / sizeof(zg::BaseField<F>::type)),    \
+                                &zg::msm_run<F, FR>,                                              \
+                                &zg::bases_to_mont<F>,                                            \
+                                &zg::bases_generate<F, FR, GEN>,                                  \
+                                &zg::host_group_op<F, FR>,                                        \
+                                &zg::host_convert_thunk<F>};                    \
+    return &ops;                                                                                  \
+  }
