@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BN254 (alt_bn128) G1 multi-scalar multiplication of 2^24 points (BASELINE.json
+configs[1]/[2]) through the C ABI, inputs resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one MSM over the whole 2^24-point job.  With N ranks the job is sharded by point range (rank g
+holds bases [g n/N, (g+1) n/N) resident), each rank reduces its shard to one affine point, the N partial points
+(64 B each) are all-gathered over RCCL as raw bytes and added on the host: strong scaling, the reference's
+"sum over OpenMP chunks" (SURVEY.md 8e).  Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAC_PER_POINT_BN254_G1 = 21760  # 16 windows x 10 field mults x 136 32-bit MACs
+PEAK_MAC_PER_S = 3.4e13  # v_mad_u64_u32 issue rate measured on MI355X by tools/peak_imul.hip (profiles/)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
+
+
+def cpu_baseline(bases, scalars_dev, sample_n, r):
+    """Times the CPU restatement of libff multi_exp<BDLO12> (oracle/zeth_cpu.cpp) on the first sample_n
+    points of the same workload, OpenMP chunks = threads, and checks it against the GPU on that sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes
+
+    import cpu_oracle
+    import zeth_amd.lib as zl
+
+    threads = min(16, cpu_oracle.max_threads())
+    cpu_oracle.lib().oz_set_threads(threads)
+    ab = 64
+    buf = ctypes.create_string_buffer(sample_n * ab)
+    zl._check(zl.load_library().zg_bases_read(bases._h, 0, sample_n, zl.FORM_PLAIN, buf))
+    sc = scalars_dev[:sample_n].cpu().contiguous().numpy().tobytes()
+    cpu_pt, sec = cpu_oracle.msm_bytes(0, 1, buf.raw, sc, sample_n, method=0, chunks=threads)
+    gpu_pt = bases.msm(scalars_dev.data_ptr(), n=sample_n)
+    if cpu_pt != gpu_pt:
+        raise SystemExit("cpu_baseline: GPU and CPU oracle disagree on the %d-point sample" % sample_n)
+    return {
+        "value": sample_n / sec,
+        "unit": "points/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "first 2^%d points of the same bases/scalars, libff-style multi_exp<BDLO12> with %d OpenMP chunks, "
+        "%.2f s; result equal to the GPU's on that sample" % (sample_n.bit_length() - 1, threads, sec),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=24)
+    ap.add_argument("--cpu-log-n", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import zeth_amd
+    from zeth_amd.synth import closed_form_scalar, random_scalars_device
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from zeth_model import BN254  # checker only: expected point from the closed form
+
+    C = BN254
+    n_total = 1 << args.log_n
+    if n_total % world:
+        raise SystemExit("2^%d points do not split over %d ranks" % (args.log_n, world))
+    n_local = n_total // world
+    first = rank * n_local
+    t0, d = 0x5A4554480000000100000000DEADBEEF, 0x5A45544800000002FEEDFACECAFEF00D
+
+    ctx = zeth_amd.Context(local_rank)
+    ctx.set_profiling(True)
+    bases = zeth_amd.Bases.generate(ctx, zeth_amd.ALT_BN128, zeth_amd.G1, n_local, (t0 + first * d) % C.r, d)
+    scalars = random_scalars_device(n_local, C.r, seed=0x5A45 + rank)
+    torch.cuda.synchronize()
+
+    gather_in = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gather_out = torch.zeros(64 * world, dtype=torch.uint8, device="cuda")
+
+    def step():
+        part = bases.msm(scalars.data_ptr(), n=n_local)
+        if world == 1:
+            return part
+        gather_in.copy_(torch.frombuffer(bytearray(zeth_amd.lib.encode_point(0, 1, part)), dtype=torch.uint8))
+        dist.all_gather_into_tensor(gather_out, gather_in)
+        raw = gather_out.cpu().numpy().tobytes()
+        acc = None
+        for g in range(world):
+            acc = zeth_amd.host_group_op(0, 1, "add", acc, zeth_amd.lib.decode_point(0, 1, raw[64 * g : 64 * g + 64]))
+        return acc
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    fence()
+    accum_ms = []
+    phase_ms = {}
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        for name, ms in ctx.last_timings():
+            phase_ms[name] = phase_ms.get(name, 0.0) + ms
+            if name == "accum":
+                accum_ms.append(ms)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of the whole job (outside the timed region): closed form (sum a_i (t0 + i d)) G
+    k_local = closed_form_scalar(scalars, (t0 + first * d) % C.r, d, C.r)
+    if world > 1:
+        ks = [None] * world
+        dist.all_gather_object(ks, k_local)
+        k = sum(ks) % C.r
+    else:
+        k = k_local
+    expect = C.G1.mul(k, C.G1.gen)
+    if result != expect:
+        raise SystemExit("bench.py: MSM result does not match the closed form")
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        k_ms = sum(accum_ms) / len(accum_ms)
+        achieved = n_local * MAC_PER_POINT_BN254_G1 / (k_ms * 1e-3)
+        # algorithmic HBM bytes of the accumulation kernel: per (point, window) one 64 B base + one 4 B sorted entry
+        hbm_bytes = n_local * 16 * 68
+        out = {
+            "metric": "bn254_g1_msm_2^%d_throughput" % args.log_n,
+            "value": n_total / (elapsed / args.steps),
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BN254 G1 MSM, 2^%d points P_i=(t0+i*d)G resident in HBM, scalars uniform mod r resident in HBM, "
+                "result affine on host" % args.log_n,
+                "sharding": "point range over %d rank(s); 64 B partials all-gathered" % world,
+                "verified": "closed form (sum a_i t_i) G",
+            },
+            "roofline": {
+                "bound": "valu_int32_mul",
+                "kernel": "k_accum (bucket accumulation, XYZZ mixed add)",
+                "achieved": achieved / 1e12,
+                "peak": PEAK_MAC_PER_S / 1e12,
+                "unit": "TMAC/s",
+                "frac": achieved / PEAK_MAC_PER_S,
+                "kernel_ms": k_ms,
+                "traffic": None,
+                "hbm_algorithmic_GBps": hbm_bytes / (k_ms * 1e-3) / 1e9,
+                "hbm_frac": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "MSM is integer-multiply bound (SURVEY 8d): achieved = 21760 MAC/point x points / kernel time; peak = "
+                "measured v_mad_u64_u32 rate",
+            },
+            "phases_ms": {k2: v / args.steps for k2, v in phase_ms.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(bases, scalars, min(n_local, 1 << args.cpu_log_n), C.r)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

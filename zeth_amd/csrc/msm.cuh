@@ -158,7 +158,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t cap, uint32_t* __restrict__ cursor /* absolute positions */,
                                                 uint32_t* __restrict__ boff /* bucket start, absolute */,
                                                 uint32_t* __restrict__ ufirst /* first unit, absolute */,
-                                                uint32_t* __restrict__ wunits) {
+                                                uint32_t* __restrict__ wunits /* [W] unit totals, [W] = max units per bucket */) {
   __shared__ uint32_t sa[1024], sb[1024];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   const uint32_t per = (nb + 1023) / 1024;
@@ -170,6 +170,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
       uint32_t v = cnt[(size_t)w * nb + b];
       ca += v;
       cb += (v + L - 1) / L;
+      if (v > L) atomicMax(&wunits[gridDim.x], (v + L - 1) / L);
     }
   }
   sa[tid] = ca;
@@ -292,6 +293,29 @@ __global__ void __launch_bounds__(256) k_accum(const UnitDesc* __restrict__ unit
   part[u] = acc;
 }
 
+// Buckets that were split into several units (skewed scalars: 0/1-heavy witnesses, short top windows) are
+// folded by a pairwise tree, one launch per level: part[u0 + i] += part[u0 + i + s] for i % 2s == 0.
+template <class F>
+__global__ void __launch_bounds__(256) k_combine(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
+                                                  uint32_t W, uint32_t cap, const uint32_t* __restrict__ cnt,
+                                                  const uint32_t* __restrict__ ufirst, uint32_t L, uint32_t s,
+                                                  XYZZ<F>* __restrict__ part) {
+  if (s >= wunits[W]) return;  // no bucket has more than s units
+  const uint32_t w = blockIdx.y;
+  const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ul >= wunits[w]) return;
+  const uint32_t u = w * cap + ul;
+  const uint32_t b = units[u].bucket;
+  const uint32_t i = u - ufirst[b];
+  const uint32_t nu = (cnt[b] + L - 1) / L;
+  if ((i & (2 * s - 1)) == 0 && i + s < nu) {
+    XYZZ<F> a = part[u];
+    XYZZ<F> c = part[u + s];
+    xyzz_add(a, c);
+    part[u] = a;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bucket reduction
 // ---------------------------------------------------------------------------------------------
@@ -306,10 +330,7 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
   XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
   for (int bb = (int)k - 1; bb >= 0; bb--) {
     size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
-    uint32_t v = cnt[gid];
-    uint32_t nu = (v + L - 1) / L;
-    uint32_t u0 = ufirst[gid];
-    for (uint32_t s = 0; s < nu; s++) xyzz_add(run, part[u0 + s]);
+    if (cnt[gid]) xyzz_add(run, part[ufirst[gid]]);  // k_combine left the bucket sum in its first unit
     xyzz_add(tot, run);
   }
   // tot = sum (b - j*k + 1) B_b ; add (j*k) * run

@@ -140,7 +140,7 @@ int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars,
   if ((uint64_t)p.W * (uint64_t)n >= (1ull << 32)) return ZG_ERR_UNSUPPORTED;
   const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
   size_t need = zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
-                zg_ctx::ws_round(p.W * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
+                zg_ctx::ws_round((p.W + 1) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
   ZG_TRY(ctx->ws_reserve(need));
   int16_t* dig = ctx->ws_take<int16_t>(WN);
@@ -149,7 +149,7 @@ int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars,
   uint32_t* cursor = ctx->ws_take<uint32_t>(WB);
   uint32_t* boff = ctx->ws_take<uint32_t>(WB);
   uint32_t* ufirst = ctx->ws_take<uint32_t>(WB);
-  uint32_t* wunits = ctx->ws_take<uint32_t>(p.W);
+  uint32_t* wunits = ctx->ws_take<uint32_t>(p.W + 1);
   UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
   XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)p.W * p.T);
@@ -167,6 +167,7 @@ int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars,
   ctx->prof_begin();
   ctx->mark("digits");
   ZG_HIP(hipMemsetAsync(cnt, 0, WB * 4, st));
+  ZG_HIP(hipMemsetAsync(wunits, 0, (p.W + 1) * 4, st));
   hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
                      p.c, p.W, p.K, dig);
   ctx->mark("hist");
@@ -181,6 +182,10 @@ int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars,
   ctx->mark("accum");
   hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, p.cap, sorted,
                      d_bases, part);
+  ctx->mark("combine");
+  for (uint32_t s = 1; s < (uint32_t)((n + p.L - 1) / p.L); s <<= 1)
+    hipLaunchKernelGGL((k_combine<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
+                       p.cap, cnt, ufirst, p.L, s, part);
   ctx->mark("reduce1");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
                      p.k, p.L, (uint32_t)p.W, seg);
