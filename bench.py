@@ -23,7 +23,7 @@ PEAK_MAC_PER_S = 3.4e13  # v_mad_u64_u32 issue rate measured on MI355X by tools/
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
 
 
-def cpu_baseline(bases, scalars_dev, sample_n, r):
+def cpu_baseline(bases, scalars_dev, sample_n):
     """Times the CPU restatement of libff multi_exp<BDLO12> (oracle/zeth_cpu.cpp) on the first sample_n
     points of the same workload, OpenMP chunks = threads, and checks it against the GPU on that sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -37,9 +37,9 @@ def cpu_baseline(bases, scalars_dev, sample_n, r):
     ab = 64
     buf = ctypes.create_string_buffer(sample_n * ab)
     zl._check(zl.load_library().zg_bases_read(bases._h, 0, sample_n, zl.FORM_PLAIN, buf))
-    sc = scalars_dev[:sample_n].cpu().contiguous().numpy().tobytes()
+    sc = scalars_dev.download(32 * sample_n)
     cpu_pt, sec = cpu_oracle.msm_bytes(0, 1, buf.raw, sc, sample_n, method=0, chunks=threads)
-    gpu_pt = bases.msm(scalars_dev.data_ptr(), n=sample_n)
+    gpu_pt = bases.msm(scalars_dev, n=sample_n)
     if cpu_pt != gpu_pt:
         raise SystemExit("cpu_baseline: GPU and CPU oracle disagree on the %d-point sample" % sample_n)
     return {
@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=24)
-    ap.add_argument("--cpu-log-n", type=int, default=18)
+    ap.add_argument("--cpu-log-n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,7 +77,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import zeth_amd
-    from zeth_amd.synth import closed_form_scalar, random_scalars_device
+    from zeth_amd.synth import closed_form_scalar, random_scalars_host
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from zeth_model import BN254  # checker only: expected point from the closed form
@@ -93,14 +93,14 @@ def main():
     ctx = zeth_amd.Context(local_rank)
     ctx.set_profiling(True)
     bases = zeth_amd.Bases.generate(ctx, zeth_amd.ALT_BN128, zeth_amd.G1, n_local, (t0 + first * d) % C.r, d)
-    scalars = random_scalars_device(n_local, C.r, seed=0x5A45 + rank)
-    torch.cuda.synchronize()
+    seed = 0x5A455448 + (rank << 32)
+    scalars = zeth_amd.DeviceBuffer.random_scalars(ctx, zeth_amd.ALT_BN128, n_local, seed)  # resident in HBM
 
     gather_in = torch.zeros(64, dtype=torch.uint8, device="cuda")
     gather_out = torch.zeros(64 * world, dtype=torch.uint8, device="cuda")
 
     def step():
-        part = bases.msm(scalars.data_ptr(), n=n_local)
+        part = bases.msm(scalars, n=n_local)
         if world == 1:
             return part
         gather_in.copy_(torch.frombuffer(bytearray(zeth_amd.lib.encode_point(0, 1, part)), dtype=torch.uint8))
@@ -138,7 +138,13 @@ def main():
         elapsed = float(t.item())
 
     # correctness of the whole job (outside the timed region): closed form (sum a_i (t0 + i d)) G
-    k_local = closed_form_scalar(scalars, (t0 + first * d) % C.r, d, C.r)
+    words = random_scalars_host(n_local, C.r, seed)
+    import numpy as np
+
+    probe = np.frombuffer(scalars.download(32 * 4096), dtype=np.uint64).reshape(-1, 4)
+    if not np.array_equal(probe, words[:4096]):
+        raise SystemExit("bench.py: host mirror of the scalar generator disagrees with the device")
+    k_local = closed_form_scalar(words, (t0 + first * d) % C.r, d, C.r)
     if world > 1:
         ks = [None] * world
         dist.all_gather_object(ks, k_local)
@@ -147,7 +153,9 @@ def main():
         k = k_local
     expect = C.G1.mul(k, C.G1.gen)
     if result != expect:
-        raise SystemExit("bench.py: MSM result does not match the closed form")
+        again = step()
+        raise SystemExit("bench.py: MSM result does not match the closed form (rerun equal to first: %s, rerun correct: %s)"
+                         % (again == result, again == expect))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -191,7 +199,7 @@ def main():
             "phases_ms": {k2: v / args.steps for k2, v in phase_ms.items()},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(bases, scalars, min(n_local, 1 << args.cpu_log_n), C.r)
+            out["cpu_baseline"] = cpu_baseline(bases, scalars, min(n_local, 1 << args.cpu_log_n))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -58,6 +58,17 @@ void zg_ctx_destroy(zg_ctx* ctx);
 int zg_ctx_set_profiling(zg_ctx* ctx, int enabled);
 int zg_ctx_last_timings(zg_ctx* ctx, const char** names, float* ms, int max_entries, int* n_entries);
 
+/* Device buffers owned by the library (so that callers need no HIP runtime of their own to keep scalars resident
+ * in HBM; no counterpart in the reference, whose vectors live in host memory). */
+int zg_dev_malloc(zg_ctx* ctx, size_t bytes, void** dptr);
+int zg_dev_free(zg_ctx* ctx, void* dptr);
+int zg_dev_upload(zg_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int zg_dev_download(zg_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+/* benchmark input: n Fr scalars, plain form, uniform in [0, r): element i is the first value < r of
+ * the stream w(i, t) = 4 x splitmix64 words of counter (seed + i) * 2^8 + t, masked to the bit length of r,
+ * t = 0, 1, ... (rejection sampling; reproducible on the host, see zeth_amd/synth.py) */
+int zg_scalars_random(zg_ctx* ctx, int curve, void* dptr, size_t n, uint64_t seed);
+
 /* Resident base points: the device-side analogue of the keypair cache (prover_server/prover_server.cpp:436-493)
  * -- the `gs` argument of libzeth::multi_exp (libzeth/core/multi_exp.hpp:13-22) uploaded once. */
 int zg_bases_create(zg_ctx* ctx, int curve, int group, const void* points, size_t n, int form, int mem,
@@ -80,6 +91,61 @@ int zg_msm(zg_bases* bases, size_t first, const void* scalars, size_t n, int sca
 /* same, with an explicit window width (0 = automatic); test and tuning hook */
 int zg_msm_ex(zg_bases* bases, size_t first, const void* scalars, size_t n, int scalar_form, int scalars_mem,
               int out_form, void* out_affine, int window_bits);
+
+/* In-place radix-2 evaluation-domain transform of 2^log_n Fr elements (natural order in and out):
+ *   inverse = 0, coset = 0   domain.FFT(a)           inverse = 1, coset = 0   domain.iFFT(a)
+ *   inverse = 0, coset = 1   domain.cosetFFT(a, g)    inverse = 1, coset = 1   domain.icosetFFT(a, g)
+ * with g = Fr::multiplicative_generator, the only shift the prover uses.  Replaces
+ * libfqfft::basic_radix2_domain<Fr>(2^log_n) as called at libzeth/core/evaluator_from_lagrange.tcc:43
+ * (domain.iFFT(coefficients)) and inside libsnark's r1cs_to_qap_witness_map.
+ * log_n beyond the field's two-adicity (28 / 47) or this build's limit (2^24) -> ZG_ERR_UNSUPPORTED. */
+int zg_ntt(zg_ctx* ctx, int curve, void* data, unsigned log_n, int inverse, int coset, int form, int mem);
+
+/* One R1CS matrix in CSR form: row i (constraint i) holds the terms of its linear combination, `col` = variable
+ * index with 0 = the constant ONE (libsnark linear_term.index), `val` = Fr coefficient.  The on-disk equivalent is
+ * libzeth/serialization/r1cs_serialization.tcc:199-275. */
+typedef struct {
+  const uint64_t* row_ptr; /* num_constraints + 1 */
+  const uint32_t* col;     /* nnz */
+  const void* val;         /* nnz Fr elements */
+} zg_r1cs_matrix;
+
+/* Host view of r1cs_gg_ppzksnark_proving_key (libzeth/snarks/groth16/groth16_snark.hpp:18-21; fields enumerated by
+ * groth16_snark.tcc:101-110): every point affine, every element in `form`. */
+typedef struct {
+  size_t num_inputs;      /* primary input size */
+  size_t num_variables;   /* primary + auxiliary, without the constant */
+  size_t num_constraints;
+  zg_r1cs_matrix a, b, c; /* pk.constraint_system */
+  const void *alpha_g1, *beta_g1, *beta_g2, *delta_g1, *delta_g2;
+  const void* A_query; size_t A_len; /* num_variables + 1 G1 points */
+  const uint32_t* B_indices;         /* B_query is a sparse knowledge_commitment_vector<G2, G1> */
+  const void* B_g2; const void* B_g1; size_t B_len;
+  const void* H_query; size_t H_len; /* domain size - 1 */
+  const void* L_query; size_t L_len; /* num_variables - num_inputs */
+  int form;
+} zg_pk_view;
+
+/* Uploads the proving key once (bases to HBM in Montgomery affine form, constraint matrices as CSR) and allocates
+ * the per-proof device scratch: the analogue of loading the keypair before proving (zeth_tool/prove_cmd.cpp:39-43,
+ * prover_server/prover_server.cpp:449-493).  Size mismatches -> ZG_ERR_INVALID_ARGUMENT. */
+int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out);
+void zg_pk_free(zg_pk* pk);
+int zg_pk_domain_size(const zg_pk* pk, size_t* m);
+
+/* Replaces groth16_snark<ppT>::generate_proof(pk, primary_input, auxiliary_input)
+ * (libzeth/snarks/groth16/groth16_snark.hpp:37-40, .tcc:36-46) = libsnark::r1cs_gg_ppzksnark_prover(pk, primary,
+ * aux, force_pow_2_domain = true), with the prover randomness (r, s) passed in (Fr, plain, 32 B each) so that the
+ * proof is reproducible.  proof_out receives g_A || g_B || g_C affine in out_form (256 B alt_bn128, 384 B
+ * BLS12-377).  n_primary != pk.num_inputs or n_primary + n_aux != pk.num_variables -> ZG_ERR_INVALID_ARGUMENT;
+ * an assignment that does not satisfy the constraints is NOT an error (it yields a proof that fails to verify,
+ * as in the reference: libzeth/tests/prover/prover_test.cpp:703-714). */
+int zg_prove(zg_pk* pk, const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form, const void* r,
+             const void* s, int out_form, void* proof_out);
+/* libsnark::r1cs_to_qap_witness_map(cs, primary, aux, 0, 0, 0, true).coefficients_for_H: writes domain size + 1
+ * Fr elements to h_out (host). */
+int zg_witness_map(zg_pk* pk, const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
+                   int out_form, void* h_out);
 
 /* group-law helpers on the host tail (same code the library uses to finish an MSM / assemble a proof);
  * exported so tests can pin it without a GPU.  op: 0 = a + b, 1 = k * a (k: Fr plain 32 B in `b`) */

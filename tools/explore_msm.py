@@ -1,9 +1,9 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-import torch
+import numpy as np
 import zeth_amd
-from zeth_amd.synth import random_scalars_device, closed_form_scalar
+from zeth_amd.synth import random_scalars_host, closed_form_scalar
 from zeth_model import BN254, BLS12_377
 
 curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -19,14 +19,13 @@ for lg in logs:
     t = time.time()
     bases = zeth_amd.Bases.generate(ctx, curve, group, n, t0, d)
     tg = time.time() - t
-    sc = random_scalars_device(n, C.r, seed=lg)
-    torch.cuda.synchronize()
+    sc = zeth_amd.DeviceBuffer.random_scalars(ctx, curve, n, lg)
     res = None
     for it in range(3):
         t = time.time()
-        res = bases.msm(sc.data_ptr(), n=n)
+        res = bases.msm(sc, n=n)
         dt = time.time() - t
-    k = closed_form_scalar(sc, t0, d, C.r)
+    k = closed_form_scalar(random_scalars_host(n, C.r, lg), t0, d, C.r)
     ok = res == G.mul(k, G.gen)
     print("n=2^%d gen %.2fs msm %.2f ms ok=%s" % (lg, tg, dt * 1e3, ok), " ".join("%s=%.3f" % x for x in ctx.last_timings()), flush=True)
-    bases.free()
+    bases.free(); sc.free()

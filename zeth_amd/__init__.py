@@ -10,6 +10,10 @@ from .lib import (  # noqa: F401
     G2,
     Bases,
     Context,
+    DeviceBuffer,
+    EvaluationDomain,
+    Groth16Snark,
+    ProvingKey,
     ZethGpuError,
     host_group_op,
     load_library,

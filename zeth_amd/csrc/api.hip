@@ -63,6 +63,7 @@ void zg_ctx_destroy(zg_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  for (auto& kv : c->ntt_domains) delete kv.second;
   if (c->ws) hipFree(c->ws);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -83,6 +84,88 @@ int zg_ctx_last_timings(zg_ctx* c, const char** names, float* ms, int max_entrie
     if (ms) ms[i] = c->last_ms[i];
   }
   *n_entries = n;
+  return ZG_OK;
+}
+
+int zg_dev_malloc(zg_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  ZG_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+  return ZG_OK;
+}
+int zg_dev_free(zg_ctx* ctx, void* dptr) {
+  if (!ctx) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  if (dptr) ZG_HIP(hipFree(dptr));
+  return ZG_OK;
+}
+int zg_dev_upload(zg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  ZG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  return ZG_OK;
+}
+int zg_dev_download(zg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  ZG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  return ZG_OK;
+}
+
+__device__ __forceinline__ uint64_t zg_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+struct ZgModulus {
+  uint64_t p[4];
+  uint64_t top_mask;
+};
+static __global__ void __launch_bounds__(256) k_scalars_random(uint64_t* __restrict__ out, size_t n, uint64_t seed,
+                                                                ZgModulus m) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (uint64_t t = 0; t < 256; t++) {
+    uint64_t ctr = ((seed + i) << 8) + t;
+    uint64_t w[4];
+    for (int k = 0; k < 4; k++) w[k] = zg_splitmix64(ctr * 4 + k);
+    w[3] &= m.top_mask;
+    bool lt = false;
+    for (int k = 3; k >= 0; k--) {
+      if (w[k] != m.p[k]) {
+        lt = w[k] < m.p[k];
+        break;
+      }
+    }
+    if (lt || t == 255) {
+      if (!lt) w[3] = 0;  // unreachable in practice (probability 2^-256)
+      for (int k = 0; k < 4; k++) out[4 * i + k] = w[k];
+      return;
+    }
+  }
+}
+int zg_scalars_random(zg_ctx* ctx, int curve, void* dptr, size_t n, uint64_t seed) {
+  if (!ctx || (n && !dptr)) return ZG_ERR_INVALID_ARGUMENT;
+  ZgModulus m;
+  if (curve == ZG_CURVE_ALT_BN128) {
+    m = ZgModulus{{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull},
+                  0x3fffffffffffffffull};
+  } else if (curve == ZG_CURVE_BLS12_377) {
+    m = ZgModulus{{0x0a11800000000001ull, 0x59aa76fed0000001ull, 0x60b44d1e5c37b001ull, 0x12ab655e9a2ca556ull},
+                  0x1fffffffffffffffull};
+  } else {
+    return ZG_ERR_INVALID_ARGUMENT;
+  }
+  if (!n) return ZG_OK;
+  ZG_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_scalars_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)dptr, n,
+                     seed, m);
+  ZG_HIP(hipGetLastError());
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
   return ZG_OK;
 }
 
@@ -203,6 +286,73 @@ int zg_msm_ex(zg_bases* b, size_t first, const void* scalars, size_t n, int scal
 int zg_msm(zg_bases* b, size_t first, const void* scalars, size_t n, int scalar_form, int scalars_mem, int out_form,
            void* out_affine) {
   return zg_msm_ex(b, first, scalars, n, scalar_form, scalars_mem, out_form, out_affine, 0);
+}
+
+int zg_ntt(zg_ctx* ctx, int curve, void* data, unsigned log_n, int inverse, int coset, int form, int mem) {
+  const FrOps* ops = zg_fr_ops(curve);
+  if (!ctx || !ops || !data || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT) ||
+      (mem != ZG_MEM_HOST && mem != ZG_MEM_DEVICE))
+    return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  const size_t bytes = ((size_t)32) << log_n;
+  if (log_n > 28) return ZG_ERR_UNSUPPORTED;
+  if (mem == ZG_MEM_DEVICE) return ops->ntt_inplace(ctx, curve, data, log_n, inverse != 0, coset != 0, form);
+  void* d = nullptr;
+  ZG_HIP(hipMalloc(&d, bytes));
+  int s = ZG_OK;
+  if (hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = ZG_ERR_HIP;
+  if (s == ZG_OK) s = ops->ntt_inplace(ctx, curve, d, log_n, inverse != 0, coset != 0, form);
+  if (s == ZG_OK && hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = ZG_ERR_HIP;
+  hipFree(d);
+  return s;
+}
+
+int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out) {
+  const FrOps* ops = zg_fr_ops(curve);
+  if (!ctx || !ops || !view || !out) return ZG_ERR_INVALID_ARGUMENT;
+  if (view->form != ZG_FORM_PLAIN && view->form != ZG_FORM_MONT) return ZG_ERR_INVALID_ARGUMENT;
+  if (!view->alpha_g1 || !view->beta_g1 || !view->beta_g2 || !view->delta_g1 || !view->delta_g2) return ZG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  ZG_HIP(hipSetDevice(ctx->device));
+  PkBase* impl = nullptr;
+  ZG_TRY(ops->pk_create(ctx, curve, view, &impl));
+  zg_pk* pk = new (std::nothrow) zg_pk{ctx, impl};
+  if (!pk) {
+    delete impl;
+    return ZG_ERR_OUT_OF_MEMORY;
+  }
+  *out = pk;
+  return ZG_OK;
+}
+
+void zg_pk_free(zg_pk* pk) {
+  if (!pk) return;
+  delete pk->impl;
+  delete pk;
+}
+
+int zg_pk_domain_size(const zg_pk* pk, size_t* m) {
+  if (!pk || !m) return ZG_ERR_INVALID_ARGUMENT;
+  *m = pk->impl->domain_size();
+  return ZG_OK;
+}
+
+int zg_prove(zg_pk* pk, const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form, const void* r,
+             const void* s, int out_form, void* proof_out) {
+  if (!pk || !r || !s || !proof_out || (n_primary && !primary) || (n_aux && !aux)) return ZG_ERR_INVALID_ARGUMENT;
+  if ((form != ZG_FORM_PLAIN && form != ZG_FORM_MONT) || (out_form != ZG_FORM_PLAIN && out_form != ZG_FORM_MONT))
+    return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(pk->ctx->device));
+  return pk->impl->prove(primary, n_primary, aux, n_aux, form, (const uint32_t*)r, (const uint32_t*)s, out_form, proof_out);
+}
+
+int zg_witness_map(zg_pk* pk, const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
+                   int out_form, void* h_out) {
+  if (!pk || !h_out || (n_primary && !primary) || (n_aux && !aux)) return ZG_ERR_INVALID_ARGUMENT;
+  if ((form != ZG_FORM_PLAIN && form != ZG_FORM_MONT) || (out_form != ZG_FORM_PLAIN && out_form != ZG_FORM_MONT))
+    return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(pk->ctx->device));
+  return pk->impl->witness_map_out(primary, n_primary, aux, n_aux, form, out_form, h_out);
 }
 
 int zg_host_group_op(int curve, int group, int op, const void* a, const void* b, int form, void* out) {

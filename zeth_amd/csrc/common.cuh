@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -24,7 +25,12 @@
     if (_s != ZG_OK) return _s; \
   } while (0)
 
+struct NttDomainBase {
+  virtual ~NttDomainBase() {}
+};
+
 struct zg_ctx {
+  std::map<uint32_t, NttDomainBase*> ntt_domains;  // key = curve << 8 | log m
   int device = 0;
   hipStream_t stream = nullptr;
   // grow-only workspace, bump-allocated per call
@@ -104,6 +110,27 @@ struct GroupOps {
 };
 
 const GroupOps* zg_group_ops(int curve, int group);
+
+struct PkBase {
+  virtual ~PkBase() {}
+  virtual int prove(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
+                    const uint32_t* r_plain, const uint32_t* s_plain, int out_form, void* proof_out) = 0;
+  virtual int witness_map_out(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
+                              int out_form, void* h_out) = 0;
+  virtual size_t domain_size() const = 0;
+};
+
+struct zg_pk {
+  zg_ctx* ctx;
+  PkBase* impl;
+};
+
+// per-curve scalar-field entry points (fr_inst.hip)
+struct FrOps {
+  int (*ntt_inplace)(zg_ctx*, int curve, void* d_data, unsigned log_m, int inverse, int coset, int form);
+  int (*pk_create)(zg_ctx*, int curve, const zg_pk_view* view, PkBase** out);
+};
+const FrOps* zg_fr_ops(int curve);
 
 struct zg_bases {
   zg_ctx* ctx;

@@ -166,8 +166,8 @@ int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars,
   }
   ctx->prof_begin();
   ctx->mark("digits");
-  ZG_HIP(hipMemsetAsync(cnt, 0, WB * 4, st));
-  ZG_HIP(hipMemsetAsync(wunits, 0, (p.W + 1) * 4, st));
+  hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
+                     (size_t)(p.W + 1));
   hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
                      p.c, p.W, p.K, dig);
   ctx->mark("hist");

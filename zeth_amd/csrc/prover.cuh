@@ -1,0 +1,318 @@
+// Groth16 prover on the device: r1cs_to_qap_witness_map + the four query evaluations + blinding.
+//
+// Restates libsnark::r1cs_gg_ppzksnark_prover(pk, primary, aux, force_pow_2_domain = true) as Zeth calls it
+// (libzeth/snarks/groth16/groth16_snark.tcc:36-46) -- SURVEY.md 3.1 step 5:
+//   a. aA_i = <a_i, w>, aB_i = <b_i, w>, aC_i = <c_i, w> (+ the num_inputs + 1 input-consistency rows of A),
+//      iFFT, cosetFFT (x3), H = (aA o aB - aC) / Z(g), icosetFFT -> coefficients of H (m + 1, top two zero)
+//   c. At = <A_query, 1||w>, Bt = <B_query, 1||w> in G2 and G1, Ht = <H_query, H[0..m-1)>, Lt = <L_query, aux>
+//   d. g_A = alpha + At + r delta ; g1_B = beta + Bt.h + s delta ; g_B = beta2 + Bt.g + s delta2 ;
+//      g_C = Ht + Lt + s g_A + r g1_B - (r s) delta
+// (r, s) are arguments here: libsnark draws them inside the prover, Zeth's API has no hook.
+// An unsatisfied assignment is not an error: like the reference's release build it yields a proof that fails
+// verification (libzeth/tests/prover/prover_test.cpp:703-714).
+#pragma once
+#include <string.h>
+
+#include "msm_host.cuh"
+#include "ntt_host.cuh"
+
+namespace zg {
+
+struct CsrDev {
+  uint64_t* row_ptr = nullptr;
+  uint32_t* col = nullptr;
+  void* val = nullptr;  // Fr, Montgomery
+  size_t nnz = 0;
+};
+
+// w_full[0] = 1, w_full[1 + i] = assignment[i] (converted to Montgomery when the caller passed plain integers)
+template <class Fr>
+__global__ void __launch_bounds__(256) k_build_w(const Fr* __restrict__ primary, size_t n_primary,
+                                                  const Fr* __restrict__ aux, size_t n_aux, int plain,
+                                                  Fr* __restrict__ w_full) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_primary + n_aux) return;
+  Fr x;
+  if (i == 0) {
+    x = Fr::one();
+  } else {
+    x = (i - 1 < n_primary) ? glob_get(primary + (i - 1)) : glob_get(aux + (i - 1 - n_primary));
+    if (plain) x = Fr::to_mont(x);
+  }
+  glob_put(w_full + i, x);
+}
+
+// out[i] = <row_i, w> for i < nc; matrix A additionally carries w_0..w_num_inputs in rows nc..nc+num_inputs
+// (libsnark r1cs_to_qap: the extra constraints that make the A polynomials linearly independent); the rest of
+// the m-sized vector is zero.
+template <class Fr>
+__global__ void __launch_bounds__(256) k_spmv(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                               const Fr* __restrict__ val, const Fr* __restrict__ w, size_t nc, size_t m,
+                                               size_t extra_rows, Fr* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr acc = Fr::zero();
+  if (i < nc) {
+    for (uint64_t t = row_ptr[i]; t < row_ptr[i + 1]; t++) acc = Fr::add(acc, Fr::mul(glob_get(val + t), glob_get(w + col[t])));
+  } else if (i - nc < extra_rows) {
+    acc = glob_get(w + (i - nc));
+  }
+  glob_put(out + i, acc);
+}
+
+template <class Fr>
+__global__ void __launch_bounds__(256) k_h_pointwise(Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
+                                                      Fr z_inv, size_t m) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr x = Fr::sub(Fr::mul(glob_get(a + i), glob_get(b + i)), glob_get(c + i));
+  glob_put(a + i, Fr::mul(x, z_inv));
+}
+
+template <class Fr>
+__global__ void __launch_bounds__(256) k_gather(const Fr* __restrict__ w, const uint32_t* __restrict__ idx, size_t n,
+                                                 Fr* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  glob_put(out + i, glob_get(w + idx[i]));
+}
+
+template <class Fq, class Fq2T, class Fr>
+struct ProvingKeyDev : PkBase {
+  zg_ctx* ctx = nullptr;
+  int curve = 0;
+  size_t num_inputs = 0, num_vars = 0, nc = 0, m = 0;
+  unsigned log_m = 0;
+  CsrDev mat[3];
+  Affine<Fq> alpha_g1, beta_g1, delta_g1;  // Montgomery, host
+  Affine<Fq2T> beta_g2, delta_g2;
+  Affine<Fq>*A = nullptr, *B1 = nullptr, *H = nullptr, *L = nullptr;
+  Affine<Fq2T>* B2 = nullptr;
+  uint32_t* B_idx = nullptr;
+  size_t A_len = 0, B_len = 0, H_len = 0, L_len = 0;
+  // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
+  Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
+  Fr z_inv;
+
+  ~ProvingKeyDev() override {
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& M : mat) {
+      hipFree(M.row_ptr);
+      hipFree(M.col);
+      hipFree(M.val);
+    }
+    hipFree(A); hipFree(B1); hipFree(B2); hipFree(H); hipFree(L); hipFree(B_idx);
+    hipFree(w); hipFree(ev[0]); hipFree(ev[1]); hipFree(ev[2]); hipFree(tmp); hipFree(bsc); hipFree(assign);
+  }
+
+  template <class T>
+  int dev_copy(T** dst, const void* src, size_t count) {
+    *dst = nullptr;
+    ZG_HIP(hipMalloc((void**)dst, (count ? count : 1) * sizeof(T)));
+    if (count) ZG_HIP(hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return ZG_OK;
+  }
+
+  int create(zg_ctx* c, int curve_, const zg_pk_view* v) {
+    ctx = c;
+    curve = curve_;
+    num_inputs = v->num_inputs;
+    num_vars = v->num_variables;
+    nc = v->num_constraints;
+    if (num_inputs > num_vars) return ZG_ERR_INVALID_ARGUMENT;
+    // force_pow_2_domain = true (groth16_snark.tcc:43-45): smallest power of two >= nc + num_inputs + 1
+    m = 2;
+    log_m = 1;
+    while (m < nc + num_inputs + 1) {
+      m <<= 1;
+      log_m++;
+    }
+    if (v->A_len != num_vars + 1 || v->H_len != m - 1 || v->L_len != num_vars - num_inputs || v->B_len > num_vars + 1)
+      return ZG_ERR_INVALID_ARGUMENT;
+    const zg_r1cs_matrix* src[3] = {&v->a, &v->b, &v->c};
+    const int plain = v->form == ZG_FORM_PLAIN;
+    hipStream_t st = ctx->stream;
+    for (int k = 0; k < 3; k++) {
+      if (nc && (!src[k]->row_ptr || src[k]->row_ptr[0] != 0)) return ZG_ERR_INVALID_ARGUMENT;
+      size_t nnz = nc ? (size_t)src[k]->row_ptr[nc] : 0;
+      for (size_t i = 0; i < nc; i++)
+        if (src[k]->row_ptr[i] > src[k]->row_ptr[i + 1]) return ZG_ERR_INVALID_ARGUMENT;
+      for (size_t t = 0; t < nnz; t++)
+        if (src[k]->col[t] > num_vars) return ZG_ERR_INVALID_ARGUMENT;
+      mat[k].nnz = nnz;
+      std::vector<uint64_t> zero_rows;
+      const uint64_t* rp = src[k]->row_ptr;
+      if (!nc) {
+        zero_rows.assign(1, 0);
+        rp = zero_rows.data();
+      }
+      ZG_TRY(dev_copy(&mat[k].row_ptr, rp, nc + 1));
+      ZG_TRY(dev_copy(&mat[k].col, src[k]->col, nnz));
+      Fr* val = nullptr;
+      ZG_TRY(dev_copy(&val, src[k]->val, nnz));
+      mat[k].val = val;
+      if (plain && nnz)
+        hipLaunchKernelGGL((k_fr_convert<Fr>), dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, val, nnz, 1);
+    }
+    const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
+    const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
+    auto up1 = [&](Affine<Fq>** dst, const void* s, size_t n) -> int {
+      ZG_TRY(dev_copy(dst, s, n));
+      if (plain && n) ZG_TRY(o1->to_mont(ctx, *dst, n));
+      return ZG_OK;
+    };
+    ZG_TRY(up1(&A, v->A_query, v->A_len));
+    ZG_TRY(up1(&B1, v->B_g1, v->B_len));
+    ZG_TRY(up1(&H, v->H_query, v->H_len));
+    ZG_TRY(up1(&L, v->L_query, v->L_len));
+    ZG_TRY(dev_copy(&B2, v->B_g2, v->B_len));
+    if (plain && v->B_len) ZG_TRY(o2->to_mont(ctx, B2, v->B_len));
+    for (size_t i = 0; i < v->B_len; i++)
+      if (v->B_indices[i] > num_vars) return ZG_ERR_INVALID_ARGUMENT;
+    ZG_TRY(dev_copy(&B_idx, v->B_indices, v->B_len));
+    A_len = v->A_len; B_len = v->B_len; H_len = v->H_len; L_len = v->L_len;
+    memcpy(&alpha_g1, v->alpha_g1, sizeof(alpha_g1));
+    memcpy(&beta_g1, v->beta_g1, sizeof(beta_g1));
+    memcpy(&delta_g1, v->delta_g1, sizeof(delta_g1));
+    memcpy(&beta_g2, v->beta_g2, sizeof(beta_g2));
+    memcpy(&delta_g2, v->delta_g2, sizeof(delta_g2));
+    if (plain) {
+      host_affine_convert(&alpha_g1, 1, 1);
+      host_affine_convert(&beta_g1, 1, 1);
+      host_affine_convert(&delta_g1, 1, 1);
+      host_affine_convert(&beta_g2, 1, 1);
+      host_affine_convert(&delta_g2, 1, 1);
+    }
+    ZG_HIP(hipMalloc((void**)&w, (num_vars + 1) * sizeof(Fr)));
+    for (int k = 0; k < 3; k++) ZG_HIP(hipMalloc((void**)&ev[k], m * sizeof(Fr)));
+    ZG_HIP(hipMalloc((void**)&tmp, m * sizeof(Fr)));
+    ZG_HIP(hipMalloc((void**)&bsc, (B_len ? B_len : 1) * sizeof(Fr)));
+    ZG_HIP(hipMalloc((void**)&assign, (num_vars ? num_vars : 1) * sizeof(Fr)));
+    // 1 / Z(g) = 1 / (g^m - 1)   (divide_by_Z_on_coset)
+    using P = typename Fr::Params;
+    Fr g = fr_from_limbs<Fr>(P::GEN_MONT);
+    z_inv = Fr::inv(Fr::sub(host_pow_u64(g, m), Fr::one()));
+    NttDomain<Fr>* D = nullptr;
+    ZG_TRY(ntt_get_domain<Fr>(ctx, curve, log_m, &D));
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));
+    return ZG_OK;
+  }
+
+  // leaves the m + 1 coefficients of H (Montgomery; entry m is zero by construction and not stored) in `tmp`
+  // and 1||w in `w`
+  int witness_map(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form) {
+    if (n_primary != num_inputs || n_primary + n_aux != num_vars) return ZG_ERR_INVALID_ARGUMENT;
+    hipStream_t st = ctx->stream;
+    ctx->mark("upload");
+    if (n_primary) ZG_HIP(hipMemcpyAsync(assign, primary, n_primary * sizeof(Fr), hipMemcpyHostToDevice, st));
+    if (n_aux) ZG_HIP(hipMemcpyAsync(assign + n_primary, aux, n_aux * sizeof(Fr), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_build_w<Fr>), dim3((unsigned)((num_vars + 1 + 255) / 256)), dim3(256), 0, st, assign, n_primary,
+                       assign + n_primary, n_aux, form == ZG_FORM_PLAIN, w);
+    ctx->mark("spmv");
+    const unsigned mb = (unsigned)((m + 255) / 256);
+    for (int k = 0; k < 3; k++)
+      hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb), dim3(256), 0, st, mat[k].row_ptr, mat[k].col, (const Fr*)mat[k].val, w, nc, m,
+                         k == 0 ? num_inputs + 1 : (size_t)0, ev[k]);
+    NttDomain<Fr>* D = nullptr;
+    ZG_TRY(ntt_get_domain<Fr>(ctx, curve, log_m, &D));
+    for (int k = 0; k < 3; k++) {
+      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[k], tmp, 1, 0));  // iFFT
+      ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[k], 0, 1));  // cosetFFT
+    }
+    ctx->mark("pointwise");
+    hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
+    ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+  }
+
+  int prove_impl(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
+                 const uint32_t* r_plain, const uint32_t* s_plain, int out_form, void* proof_out) {
+    ZG_TRY(witness_map(primary, n_primary, aux, n_aux, form));
+    hipStream_t st = ctx->stream;
+    if (B_len) hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
+    const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
+    const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
+    Affine<Fq> At, Bt1, Ht, Lt;
+    Affine<Fq2T> Bt2;
+    // scalars are Montgomery residues in device memory
+    ZG_TRY(o1->msm(ctx, A, (const uint32_t*)w, A_len, 1, 0, ZG_FORM_MONT, &At));
+    ZG_TRY(o2->msm(ctx, B2, (const uint32_t*)bsc, B_len, 1, 0, ZG_FORM_MONT, &Bt2));
+    ZG_TRY(o1->msm(ctx, B1, (const uint32_t*)bsc, B_len, 1, 0, ZG_FORM_MONT, &Bt1));
+    ZG_TRY(o1->msm(ctx, H, (const uint32_t*)tmp, H_len, 1, 0, ZG_FORM_MONT, &Ht));
+    ZG_TRY(o1->msm(ctx, L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, 0, ZG_FORM_MONT, &Lt));
+    // host tail
+    auto X1 = [](const Affine<Fq>& p) { return XYZZ<Fq>::from_affine(p); };
+    auto X2 = [](const Affine<Fq2T>& p) { return XYZZ<Fq2T>::from_affine(p); };
+    XYZZ<Fq> gA = X1(alpha_g1);
+    xyzz_madd(gA, At);
+    xyzz_add(gA, xyzz_mul_limbs(X1(delta_g1), r_plain, Fr::N));
+    XYZZ<Fq> g1B = X1(beta_g1);
+    xyzz_madd(g1B, Bt1);
+    xyzz_add(g1B, xyzz_mul_limbs(X1(delta_g1), s_plain, Fr::N));
+    XYZZ<Fq2T> gB = X2(beta_g2);
+    xyzz_madd(gB, Bt2);
+    xyzz_add(gB, xyzz_mul_limbs(X2(delta_g2), s_plain, Fr::N));
+    Fr rf, sf;
+    memcpy(&rf, r_plain, sizeof(rf));
+    memcpy(&sf, s_plain, sizeof(sf));
+    Fr rs = Fr::from_mont(Fr::mul(Fr::to_mont(rf), Fr::to_mont(sf)));
+    XYZZ<Fq> gC = X1(Ht);
+    xyzz_madd(gC, Lt);
+    xyzz_add(gC, xyzz_mul_limbs(gA, s_plain, Fr::N));
+    xyzz_add(gC, xyzz_mul_limbs(g1B, r_plain, Fr::N));
+    xyzz_add(gC, xyzz_neg(xyzz_mul_limbs(X1(delta_g1), rs.v, Fr::N)));
+    struct {
+      Affine<Fq> a;
+      Affine<Fq2T> b;
+      Affine<Fq> c;
+    } proof;
+    proof.a = xyzz_to_affine(gA);
+    proof.b = xyzz_to_affine(gB);
+    proof.c = xyzz_to_affine(gC);
+    if (out_form == ZG_FORM_PLAIN) {
+      host_affine_convert(&proof.a, 1, 0);
+      host_affine_convert(&proof.b, 1, 0);
+      host_affine_convert(&proof.c, 1, 0);
+    }
+    memcpy(proof_out, &proof, sizeof(proof));
+    return ZG_OK;
+  }
+
+  int prove(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form, const uint32_t* r_plain,
+            const uint32_t* s_plain, int out_form, void* proof_out) override {
+    return prove_impl(primary, n_primary, aux, n_aux, form, r_plain, s_plain, out_form, proof_out);
+  }
+  int witness_map_out(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form, int out_form,
+                      void* h_out) override {
+    ZG_TRY(witness_map(primary, n_primary, aux, n_aux, form));
+    return read_h(out_form, h_out);
+  }
+  size_t domain_size() const override { return m; }
+
+  int read_h(int out_form, void* out) {
+    hipStream_t st = ctx->stream;
+    if (out_form == ZG_FORM_PLAIN)
+      hipLaunchKernelGGL((k_fr_convert<Fr>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, tmp, m, 0);
+    ZG_HIP(hipMemcpyAsync(out, tmp, m * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    memset((char*)out + m * sizeof(Fr), 0, sizeof(Fr));
+    return ZG_OK;
+  }
+};
+
+template <class Fq, class Fq2T, class Fr>
+int pk_create_impl(zg_ctx* ctx, int curve, const zg_pk_view* view, PkBase** out) {
+  auto* pk = new ProvingKeyDev<Fq, Fq2T, Fr>();
+  int s = pk->create(ctx, curve, view);
+  if (s != ZG_OK) {
+    delete pk;
+    return s;
+  }
+  *out = pk;
+  return ZG_OK;
+}
+
+}  // namespace zg

@@ -14,6 +14,24 @@ _FQ_LIMBS = {ALT_BN128: 8, BLS12_377: 12}
 _LIB = None
 
 
+class R1csMatrix(ctypes.Structure):
+    _fields_ = [("row_ptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p)]
+
+
+class PkView(ctypes.Structure):
+    _fields_ = [
+        ("num_inputs", ctypes.c_size_t), ("num_variables", ctypes.c_size_t), ("num_constraints", ctypes.c_size_t),
+        ("a", R1csMatrix), ("b", R1csMatrix), ("c", R1csMatrix),
+        ("alpha_g1", ctypes.c_void_p), ("beta_g1", ctypes.c_void_p), ("beta_g2", ctypes.c_void_p),
+        ("delta_g1", ctypes.c_void_p), ("delta_g2", ctypes.c_void_p),
+        ("A_query", ctypes.c_void_p), ("A_len", ctypes.c_size_t),
+        ("B_indices", ctypes.c_void_p), ("B_g2", ctypes.c_void_p), ("B_g1", ctypes.c_void_p), ("B_len", ctypes.c_size_t),
+        ("H_query", ctypes.c_void_p), ("H_len", ctypes.c_size_t),
+        ("L_query", ctypes.c_void_p), ("L_len", ctypes.c_size_t),
+        ("form", ctypes.c_int),
+    ]
+
+
 class ZethGpuError(RuntimeError):
     def __init__(self, status: int, what: str):
         super().__init__("zeth_gpu: %s (status %d)" % (what, status))
@@ -42,6 +60,11 @@ def load_library():
     L.zg_ctx_destroy.restype = None
     L.zg_ctx_set_profiling.argtypes = [vp, ci]
     L.zg_ctx_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
+    L.zg_dev_malloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.zg_dev_free.argtypes = [vp, vp]
+    L.zg_dev_upload.argtypes = [vp, vp, vp, sz]
+    L.zg_dev_download.argtypes = [vp, vp, vp, sz]
+    L.zg_scalars_random.argtypes = [vp, ci, vp, sz, ctypes.c_uint64]
     L.zg_bases_create.argtypes = [vp, ci, ci, vp, sz, ci, ci, ctypes.POINTER(vp)]
     L.zg_bases_generate.argtypes = [vp, ci, ci, sz, vp, vp, ctypes.POINTER(vp)]
     L.zg_bases_count.argtypes = [vp, ctypes.POINTER(sz)]
@@ -50,6 +73,13 @@ def load_library():
     L.zg_bases_free.restype = None
     L.zg_msm.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp]
     L.zg_msm_ex.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp, ci]
+    L.zg_ntt.argtypes = [vp, ci, vp, ctypes.c_uint, ci, ci, ci, ci]
+    L.zg_pk_create.argtypes = [vp, ci, ctypes.POINTER(PkView), ctypes.POINTER(vp)]
+    L.zg_pk_free.argtypes = [vp]
+    L.zg_pk_free.restype = None
+    L.zg_pk_domain_size.argtypes = [vp, ctypes.POINTER(sz)]
+    L.zg_prove.argtypes = [vp, vp, sz, vp, sz, ci, vp, vp, ci, vp]
+    L.zg_witness_map.argtypes = [vp, vp, sz, vp, sz, ci, ci, vp]
     L.zg_host_group_op.argtypes = [ci, ci, ci, vp, vp, ci, vp]
     _LIB = L
     return L
@@ -134,6 +164,49 @@ class Context:
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
 
 
+class DeviceBuffer:
+    """Device memory owned by the library (zg_dev_malloc): keeps scalars resident in HBM."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = ctypes.c_void_p()
+        _check(ctx._L.zg_dev_malloc(ctx._h, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_bytes(cls, ctx: Context, data: bytes) -> "DeviceBuffer":
+        b = cls(ctx, len(data))
+        b.upload(data)
+        return b
+
+    @classmethod
+    def random_scalars(cls, ctx: Context, curve: int, n: int, seed: int) -> "DeviceBuffer":
+        b = cls(ctx, 32 * n)
+        _check(ctx._L.zg_scalars_random(ctx._h, curve, ctypes.c_void_p(b.ptr), n, seed))
+        return b
+
+    def upload(self, data: bytes, offset: int = 0):
+        assert offset + len(data) <= self.nbytes
+        _check(self.ctx._L.zg_dev_upload(self.ctx._h, ctypes.c_void_p(self.ptr + offset), data, len(data)))
+
+    def download(self, nbytes: Optional[int] = None, offset: int = 0) -> bytes:
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(max(1, nbytes))
+        _check(self.ctx._L.zg_dev_download(self.ctx._h, out, ctypes.c_void_p(self.ptr + offset), nbytes))
+        return out.raw[:nbytes]
+
+    def free(self):
+        if self.ptr:
+            self.ctx._L.zg_dev_free(self.ctx._h, ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Bases:
     """Resident base points (the `gs` of libzeth::multi_exp, libzeth/core/multi_exp.hpp:13-22)."""
 
@@ -173,6 +246,9 @@ class Bases:
         `scalars`: sequence of ints, bytes (n x 32 B little-endian), or a device pointer int with n given."""
         ab = affine_bytes(self.curve, self.group)
         out = ctypes.create_string_buffer(ab)
+        if isinstance(scalars, DeviceBuffer):
+            n = scalars.nbytes // 32 if n is None else n
+            scalars = scalars.ptr
         if isinstance(scalars, int):
             assert n is not None
             _check(self._L.zg_msm_ex(self._h, first, ctypes.c_void_p(scalars), n, form, MEM_DEVICE, FORM_PLAIN, out, window_bits))
@@ -193,6 +269,146 @@ class Bases:
             self.free()
         except Exception:
             pass
+
+
+class EvaluationDomain:
+    """Mirror of libfqfft::basic_radix2_domain<Fr>(m) as Zeth uses it (evaluator_from_lagrange.tcc:43,
+    powersoftau_utils.tcc:849-851): FFT / iFFT / cosetFFT / icosetFFT in place, natural order."""
+
+    def __init__(self, ctx: Context, curve: int, m: int):
+        if m < 1 or m & (m - 1):
+            raise ValueError("basic_radix2_domain: m must be a power of two")
+        self.ctx, self.curve, self.m, self.log_m = ctx, curve, m, m.bit_length() - 1
+
+    def _run(self, values, inverse: bool, coset: bool):
+        if isinstance(values, DeviceBuffer):
+            assert values.nbytes == 32 * self.m
+            _check(self.ctx._L.zg_ntt(self.ctx._h, self.curve, ctypes.c_void_p(values.ptr), self.log_m, int(inverse),
+                                      int(coset), FORM_PLAIN, MEM_DEVICE))
+            return values
+        assert len(values) == self.m
+        buf = ctypes.create_string_buffer(encode_scalars(values), 32 * self.m)
+        _check(self.ctx._L.zg_ntt(self.ctx._h, self.curve, buf, self.log_m, int(inverse), int(coset), FORM_PLAIN, MEM_HOST))
+        raw = buf.raw
+        return [le_to_int(raw[32 * i : 32 * i + 32]) for i in range(self.m)]
+
+    def FFT(self, a):
+        return self._run(a, False, False)
+
+    def iFFT(self, a):
+        return self._run(a, True, False)
+
+    def cosetFFT(self, a):
+        return self._run(a, False, True)
+
+    def icosetFFT(self, a):
+        return self._run(a, True, True)
+
+
+def csr_from_rows(rows, r: int):
+    """rows: list of {variable index: coefficient} (index 0 = constant one) -> (row_ptr, col, val) ctypes buffers."""
+    import array
+
+    rp = array.array("Q", [0])
+    cols = array.array("I")
+    vals = bytearray()
+    for lc in rows:
+        for idx, c in sorted(lc.items()):
+            cols.append(idx)
+            vals += int_to_le(c % r, 32)
+        rp.append(len(cols))
+    return ((ctypes.c_uint64 * len(rp))(*rp), (ctypes.c_uint32 * max(1, len(cols)))(*cols),
+            ctypes.create_string_buffer(bytes(vals), max(1, len(vals))))
+
+
+class ProvingKey:
+    """Device-resident r1cs_gg_ppzksnark_proving_key (groth16_snark.hpp:18-21)."""
+
+    def __init__(self, ctx: Context, curve: int, handle, keep):
+        self.ctx, self.curve, self._h, self._keep = ctx, curve, handle, keep
+        m = ctypes.c_size_t()
+        _check(ctx._L.zg_pk_domain_size(handle, ctypes.byref(m)))
+        self.domain_size = m.value
+
+    @classmethod
+    def from_model(cls, ctx: Context, curve: int, pk, r: int) -> "ProvingKey":
+        """pk: an object with the fields of the oracle's ProvingKey (alpha_g1 ... L_query, cs)."""
+        cs = pk.cs
+        keep = []
+
+        def buf(b: bytes):
+            cb = ctypes.create_string_buffer(b, max(1, len(b)))
+            keep.append(cb)
+            return ctypes.cast(cb, ctypes.c_void_p)
+
+        def g1(pts):
+            return buf(b"".join(encode_point(curve, G1, P) for P in pts))
+
+        def g2(pts):
+            return buf(b"".join(encode_point(curve, G2, P) for P in pts))
+
+        mats = []
+        for k in range(3):
+            rp, col, val = csr_from_rows([con[k] for con in cs.constraints], r)
+            keep += [rp, col, val]
+            mats.append(R1csMatrix(ctypes.cast(rp, ctypes.c_void_p), ctypes.cast(col, ctypes.c_void_p), ctypes.cast(val, ctypes.c_void_p)))
+        bidx = (ctypes.c_uint32 * max(1, len(pk.B_query)))(*[e[0] for e in pk.B_query])
+        keep.append(bidx)
+        view = PkView(cs.num_inputs, cs.num_variables, cs.num_constraints, mats[0], mats[1], mats[2],
+                      g1([pk.alpha_g1]), g1([pk.beta_g1]), g2([pk.beta_g2]), g1([pk.delta_g1]), g2([pk.delta_g2]),
+                      g1(pk.A_query), len(pk.A_query),
+                      ctypes.cast(bidx, ctypes.c_void_p), g2([e[1] for e in pk.B_query]), g1([e[2] for e in pk.B_query]), len(pk.B_query),
+                      g1(pk.H_query), len(pk.H_query), g1(pk.L_query), len(pk.L_query), FORM_PLAIN)
+        h = ctypes.c_void_p()
+        _check(ctx._L.zg_pk_create(ctx._h, curve, ctypes.byref(view), ctypes.byref(h)))
+        return cls(ctx, curve, h, None)
+
+    def free(self):
+        if self._h:
+            self.ctx._L.zg_pk_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Groth16Snark:
+    """Mirror of libzeth::groth16_snark<ppT> for the proving path (groth16_snark.hpp:32-40)."""
+
+    def __init__(self, ctx: Context, curve: int):
+        self.ctx, self.curve = ctx, curve
+
+    def generate_proof(self, pk: ProvingKey, primary_input: Sequence[int], auxiliary_input: Sequence[int],
+                       r: Optional[int] = None, s: Optional[int] = None, order: Optional[int] = None):
+        """groth16_snark::generate_proof(pk, primary, auxiliary) -> (g_A, g_B, g_C).  (r, s) default to OS randomness
+        as libsnark's Fr::random_element() does; pass them for reproducible proofs."""
+        if r is None or s is None:
+            import secrets
+
+            assert order is not None, "pass the group order to draw (r, s)"
+            r, s = secrets.randbelow(order), secrets.randbelow(order)
+        n = fq_bytes(self.curve)
+        out = ctypes.create_string_buffer(8 * n)
+        pb = ctypes.create_string_buffer(encode_scalars(primary_input), max(1, 32 * len(primary_input)))
+        ab = ctypes.create_string_buffer(encode_scalars(auxiliary_input), max(1, 32 * len(auxiliary_input)))
+        _check(self.ctx._L.zg_prove(pk._h, pb, len(primary_input), ab, len(auxiliary_input), FORM_PLAIN,
+                                    int_to_le(r, 32), int_to_le(s, 32), FORM_PLAIN, out))
+        raw = out.raw
+        return (decode_point(self.curve, G1, raw[: 2 * n]), decode_point(self.curve, G2, raw[2 * n : 6 * n]),
+                decode_point(self.curve, G1, raw[6 * n :]))
+
+    def witness_map(self, pk: ProvingKey, primary_input: Sequence[int], auxiliary_input: Sequence[int]) -> List[int]:
+        """libsnark::r1cs_to_qap_witness_map(...).coefficients_for_H (domain size + 1 values)."""
+        m = pk.domain_size
+        out = ctypes.create_string_buffer(32 * (m + 1))
+        pb = ctypes.create_string_buffer(encode_scalars(primary_input), max(1, 32 * len(primary_input)))
+        ab = ctypes.create_string_buffer(encode_scalars(auxiliary_input), max(1, 32 * len(auxiliary_input)))
+        _check(self.ctx._L.zg_witness_map(pk._h, pb, len(primary_input), ab, len(auxiliary_input), FORM_PLAIN, FORM_PLAIN, out))
+        raw = out.raw
+        return [le_to_int(raw[32 * i : 32 * i + 32]) for i in range(m + 1)]
 
 
 def host_group_op(curve: int, group: int, op: str, a, b):
