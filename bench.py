@@ -62,18 +62,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the library has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # torch is plumbing for the multi-rank exchange only (RCCL all-gather of 64-byte partial results).  A single
+    # rank never imports it: every buffer is owned by the library, and the process then runs on the system ROCm
+    # runtime alone (DESIGN.md "torch and rocprofv3").
+    torch = dist = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the library has no CPU path")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import zeth_amd
@@ -96,8 +100,9 @@ def main():
     seed = 0x5A455448 + (rank << 32)
     scalars = zeth_amd.DeviceBuffer.random_scalars(ctx, zeth_amd.ALT_BN128, n_local, seed)  # resident in HBM
 
-    gather_in = torch.zeros(64, dtype=torch.uint8, device="cuda")
-    gather_out = torch.zeros(64 * world, dtype=torch.uint8, device="cuda")
+    if world > 1:
+        gather_in = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        gather_out = torch.zeros(64 * world, dtype=torch.uint8, device="cuda")
 
     def step():
         part = bases.msm(scalars, n=n_local)
@@ -112,10 +117,11 @@ def main():
         return acc
 
     def fence():
-        torch.cuda.synchronize()
+        ctx.synchronize()  # the library's stream (every zg_msm call has already returned its result to the host)
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     result = None
     for _ in range(args.warmup):

@@ -54,6 +54,9 @@ int zg_sizes(int curve, size_t* fr, size_t* fq, size_t* g1, size_t* g2);
  * HIP device; owns a stream and a grow-only device workspace. */
 int zg_ctx_create(int device, zg_ctx** out);
 void zg_ctx_destroy(zg_ctx* ctx);
+/* waits for everything queued on the context's stream (every entry point below already returns only when its
+ * host-visible results are complete; this is for callers that time a region) */
+int zg_ctx_synchronize(zg_ctx* ctx);
 /* per-kernel timing of the last MSM/NTT call (HIP events on the context's stream); names[i] are static strings */
 int zg_ctx_set_profiling(zg_ctx* ctx, int enabled);
 int zg_ctx_last_timings(zg_ctx* ctx, const char** names, float* ms, int max_entries, int* n_entries);

@@ -18,3 +18,9 @@ for n in (1024, 1 << 16):
     exp = C.G1.mul(closed_form_scalar(w, t0, d, C.r), C.G1.gen)
     raw = sc.download()
     print(n, "gen equal", raw == w.tobytes(), "dev ok", bases.msm(sc) == exp, "host ok", bases.msm(raw) == exp, "dev again", bases.msm(sc) == exp, flush=True)
+    sc2 = zeth_amd.DeviceBuffer.from_bytes(ctx, raw)
+    r2 = bases.msm(sc2)
+    r1 = bases.msm(sc)
+    print("   uploaded-buffer ok", r2 == exp, "| dev result is None:", r1 is None, "| dev == uploaded:", r1 == r2, flush=True)
+    half = bases.msm(sc, n=n // 2); halfh = bases.msm(raw[: 32 * (n // 2)])
+    print("   half dev == half host", half == halfh, flush=True)

@@ -69,6 +69,13 @@ void zg_ctx_destroy(zg_ctx* c) {
   delete c;
 }
 
+int zg_ctx_synchronize(zg_ctx* c) {
+  if (!c) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(c->device));
+  ZG_HIP(hipStreamSynchronize(c->stream));
+  return ZG_OK;
+}
+
 int zg_ctx_set_profiling(zg_ctx* c, int enabled) {
   if (!c) return ZG_ERR_INVALID_ARGUMENT;
   c->profiling = enabled != 0;

@@ -58,6 +58,7 @@ def load_library():
     L.zg_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.zg_ctx_destroy.argtypes = [vp]
     L.zg_ctx_destroy.restype = None
+    L.zg_ctx_synchronize.argtypes = [vp]
     L.zg_ctx_set_profiling.argtypes = [vp, ci]
     L.zg_ctx_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
     L.zg_dev_malloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
@@ -152,6 +153,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def synchronize(self):
+        _check(self._L.zg_ctx_synchronize(self._h))
 
     def set_profiling(self, enabled: bool):
         _check(self._L.zg_ctx_set_profiling(self._h, int(enabled)))
