@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=24)
-    ap.add_argument("--cpu-log-n", type=int, default=22)
+    ap.add_argument("--cpu-log-n", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,21 +100,11 @@ def main():
     seed = 0x5A455448 + (rank << 32)
     scalars = zeth_amd.DeviceBuffer.random_scalars(ctx, zeth_amd.ALT_BN128, n_local, seed)  # resident in HBM
 
-    if world > 1:
-        gather_in = torch.zeros(64, dtype=torch.uint8, device="cuda")
-        gather_out = torch.zeros(64 * world, dtype=torch.uint8, device="cuda")
+    from zeth_amd.distributed import all_gather_sum
 
     def step():
         part = bases.msm(scalars, n=n_local)
-        if world == 1:
-            return part
-        gather_in.copy_(torch.frombuffer(bytearray(zeth_amd.lib.encode_point(0, 1, part)), dtype=torch.uint8))
-        dist.all_gather_into_tensor(gather_out, gather_in)
-        raw = gather_out.cpu().numpy().tobytes()
-        acc = None
-        for g in range(world):
-            acc = zeth_amd.host_group_op(0, 1, "add", acc, zeth_amd.lib.decode_point(0, 1, raw[64 * g : 64 * g + 64]))
-        return acc
+        return all_gather_sum(0, 1, part, "cuda") if world > 1 else part
 
     def fence():
         ctx.synchronize()  # the library's stream (every zg_msm call has already returned its result to the host)
