@@ -14,6 +14,11 @@
 #include <stdint.h>
 
 #include "curve_constants.h"
+#include "mont_asm.h"
+
+#ifndef ZG_ASM_FIELD
+#define ZG_ASM_FIELD 1  // gfx950 inline-assembly multiplier / carry chains on the device (mont_asm.h)
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZG_HD __host__ __device__ __forceinline__
@@ -84,6 +89,17 @@ struct Fp {
     return r;
   }
   ZG_HD static Fp add(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_ASM_FIELD
+    if constexpr (N == 8 || N == 12) {
+      uint32_t p[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) p[i] = P::P[i];
+      Fp r;
+      if constexpr (N == 8) zg_mont_add_8(r.v, a.v, b.v, p);
+      else zg_mont_add_12(r.v, a.v, b.v, p);
+      return r;
+    }
+#endif
     Fp s;
     uint64_t c = 0;
 #pragma unroll
@@ -96,6 +112,17 @@ struct Fp {
   }
   ZG_HD static Fp dbl(const Fp& a) { return add(a, a); }
   ZG_HD static Fp sub(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_ASM_FIELD
+    if constexpr (N == 8 || N == 12) {
+      uint32_t p[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) p[i] = P::P[i];
+      Fp r;
+      if constexpr (N == 8) zg_mont_sub_8(r.v, a.v, b.v, p);
+      else zg_mont_sub_12(r.v, a.v, b.v, p);
+      return r;
+    }
+#endif
     Fp d;
     uint64_t br = 0;
 #pragma unroll
@@ -141,6 +168,17 @@ struct Fp {
   }
 
   ZG_HD static Fp mul(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_ASM_FIELD
+    if constexpr (N == 8 || N == 12) {
+      uint32_t p[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) p[i] = P::P[i];
+      Fp r;
+      if constexpr (N == 8) zg_mont_mul_8(r.v, a.v, b.v, p, P::INV);
+      else zg_mont_mul_12(r.v, a.v, b.v, p, P::INV);
+      return r;
+    }
+#endif
     uint32_t t[N];
 #pragma unroll
     for (int i = 0; i < N; i++) t[i] = 0;
