@@ -33,7 +33,7 @@ struct XYZZ {
 
 // 2 * (affine p), p != identity  (EFD mdbl-2008-s-1, a = 0)
 template <class F>
-ZG_HD_COLD XYZZ<F> xyzz_mdbl(const Affine<F>& p) {
+ZG_HD XYZZ<F> xyzz_mdbl(const Affine<F>& p) {
   F U = F::dbl(p.y);
   F V = F::sqr(U);
   F W = F::mul(U, V);

@@ -275,8 +275,11 @@ ZG_HD Affine<F> load_affine(const Affine<F>* __restrict__ bases, size_t idx) {
   return u.p;
 }
 
+#ifndef ZG_ACCUM_MIN_WAVES
+#define ZG_ACCUM_MIN_WAVES 1
+#endif
 template <class F>
-__global__ void __launch_bounds__(256) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
+__global__ void __launch_bounds__(256, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
                                                 uint32_t cap, const uint32_t* __restrict__ sorted,
                                                 const Affine<F>* __restrict__ bases, XYZZ<F>* __restrict__ part) {
   const uint32_t w = blockIdx.y;

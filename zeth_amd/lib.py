@@ -39,6 +39,9 @@ class ZethGpuError(RuntimeError):
 
 
 def library_path() -> str:
+    override = os.environ.get("ZETH_GPU_LIBRARY")  # developer knob: A/B a differently built library
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzeth_gpu.so")
 
 
