@@ -78,6 +78,10 @@ int zg_bases_create(zg_ctx* ctx, int curve, int group, const void* points, size_
                     zg_bases** out);
 /* benchmark/test input: P_i = (t0 + i*d) * G for the curve's generator G (t0, d: Fr, plain, 32 B) -- SURVEY 8d */
 int zg_bases_generate(zg_ctx* ctx, int curve, int group, size_t n, const void* t0, const void* d, zg_bases** out);
+/* P_i = s_i * G for n plain Fr scalars in host memory: fixed-base batch exponentiation, the operation
+ * r1cs_gg_ppzksnark_generator uses to build the A/B/H/L queries (libff::batch_exp; Zeth calls the generator at
+ * libzeth/snarks/groth16/groth16_snark.tcc:18-25).  Used here to fabricate real keys for tests and benchmarks. */
+int zg_bases_batch_exp(zg_ctx* ctx, int curve, int group, const void* scalars, size_t n, zg_bases** out);
 int zg_bases_count(const zg_bases* b, size_t* n);
 /* copy `count` points starting at `first` back to the host (affine, `form`) */
 int zg_bases_read(zg_bases* b, size_t first, size_t count, int form, void* out);

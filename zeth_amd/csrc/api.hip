@@ -236,6 +236,26 @@ int zg_bases_generate(zg_ctx* ctx, int curve, int group, size_t n, const void* t
   return ZG_OK;
 }
 
+int zg_bases_batch_exp(zg_ctx* ctx, int curve, int group, const void* scalars, size_t n, zg_bases** out) {
+  if (n && !scalars) return ZG_ERR_INVALID_ARGUMENT;
+  zg_bases* b = nullptr;
+  ZG_TRY(bases_alloc(ctx, curve, group, n, &b));
+  void* ds = nullptr;
+  int s = ZG_OK;
+  if (n) {
+    if (hipMalloc(&ds, n * 32) != hipSuccess) s = ZG_ERR_OUT_OF_MEMORY;
+    if (s == ZG_OK && hipMemcpyAsync(ds, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = ZG_ERR_HIP;
+    if (s == ZG_OK) s = b->ops->batch_exp(ctx, b->d_pts, n, (const uint32_t*)ds);
+    if (ds) hipFree(ds);
+  }
+  if (s != ZG_OK) {
+    zg_bases_free(b);
+    return s;
+  }
+  *out = b;
+  return ZG_OK;
+}
+
 int zg_bases_count(const zg_bases* b, size_t* n) {
   if (!b || !n) return ZG_ERR_INVALID_ARGUMENT;
   *n = b->n;

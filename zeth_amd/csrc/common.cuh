@@ -104,6 +104,7 @@ struct GroupOps {
              int out_form, void* out_affine_host);
   int (*to_mont)(zg_ctx*, void* d_pts, size_t n);  // plain -> Montgomery in place
   int (*generate)(zg_ctx*, void* d_pts, size_t n, const uint32_t* t0, const uint32_t* d);
+  int (*batch_exp)(zg_ctx*, void* d_pts, size_t n, const uint32_t* d_scalars_plain);
   int (*host_op)(int op, const void* a, const void* b, int form, void* out);
   // host-side conversion of `n` affine points between forms, in place (mont <-> plain)
   void (*host_convert)(void* pts, size_t n, int to_mont);

@@ -52,6 +52,19 @@ __global__ void __launch_bounds__(64) k_gen_points(Affine<F> G, Affine<F> D, Fr 
   }
 }
 
+// lane i: tmp[i] = s_i * G by double-and-add (fixed-base batch exponentiation, the shape of libff::batch_exp)
+template <class F, class Fr>
+__global__ void __launch_bounds__(64) k_batch_exp(Affine<F> G, const Fr* __restrict__ scalars, size_t n,
+                                                   XYZZ<F>* __restrict__ tmp) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = scalars[i];
+  uint32_t k[Fr::N];
+#pragma unroll
+  for (int j = 0; j < Fr::N; j++) k[j] = s.v[j];
+  tmp[i] = xyzz_mul_limbs(XYZZ<F>::from_affine(G), k, Fr::N);
+}
+
 // lane j normalises its 64 points with one shared inversion (Montgomery's trick on zzz)
 template <class F>
 __global__ void __launch_bounds__(64) k_normalize(const XYZZ<F>* __restrict__ tmp, F* __restrict__ pref, size_t n,
@@ -256,6 +269,25 @@ int bases_generate(zg_ctx* ctx, void* d_pts, size_t n, const uint32_t* t0, const
   return ZG_OK;
 }
 
+// P_i = s_i * G for n plain scalars in device memory
+template <class F, class Fr, class Gen>
+int bases_batch_exp(zg_ctx* ctx, void* d_pts, size_t n, const uint32_t* d_scalars) {
+  if (n == 0) return ZG_OK;
+  size_t need = zg_ctx::ws_round(n * sizeof(XYZZ<F>)) + zg_ctx::ws_round(n * sizeof(F));
+  ZG_TRY(ctx->ws_reserve(need));
+  XYZZ<F>* tmp = ctx->ws_take<XYZZ<F>>(n);
+  F* pref = ctx->ws_take<F>(n);
+  if (!tmp || !pref) return ZG_ERR_OUT_OF_MEMORY;
+  hipLaunchKernelGGL((k_batch_exp<F, Fr>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, Gen::gen(),
+                     reinterpret_cast<const Fr*>(d_scalars), n, tmp);
+  size_t lanes = (n + GEN_CHUNK - 1) / GEN_CHUNK;
+  hipLaunchKernelGGL((k_normalize<F>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->stream, tmp, pref, n,
+                     reinterpret_cast<Affine<F>*>(d_pts));
+  ZG_HIP(hipGetLastError());
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  return ZG_OK;
+}
+
 template <class F>
 void host_convert_thunk(void* pts, size_t n, int to_mont) {
   host_affine_convert(reinterpret_cast<Affine<F>*>(pts), n, to_mont);
@@ -296,6 +328,7 @@ struct G2Gen {
                                 &zg::msm_run<F, FR>,                                              \
                                 &zg::bases_to_mont<F>,                                            \
                                 &zg::bases_generate<F, FR, GEN>,                                  \
+                                &zg::bases_batch_exp<F, FR, GEN>,                                 \
                                 &zg::host_group_op<F, FR>,                                        \
                                 &zg::host_convert_thunk<F>};                    \
     return &ops;                                                                                  \

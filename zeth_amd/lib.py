@@ -71,6 +71,7 @@ def load_library():
     L.zg_scalars_random.argtypes = [vp, ci, vp, sz, ctypes.c_uint64]
     L.zg_bases_create.argtypes = [vp, ci, ci, vp, sz, ci, ci, ctypes.POINTER(vp)]
     L.zg_bases_generate.argtypes = [vp, ci, ci, sz, vp, vp, ctypes.POINTER(vp)]
+    L.zg_bases_batch_exp.argtypes = [vp, ci, ci, vp, sz, ctypes.POINTER(vp)]
     L.zg_bases_count.argtypes = [vp, ctypes.POINTER(sz)]
     L.zg_bases_read.argtypes = [vp, sz, sz, ci, vp]
     L.zg_bases_free.argtypes = [vp]
@@ -240,6 +241,21 @@ class Bases:
         h = ctypes.c_void_p()
         _check(ctx._L.zg_bases_generate(ctx._h, curve, group, n, int_to_le(t0, 32), int_to_le(d, 32), ctypes.byref(h)))
         return cls(ctx, curve, group, h, n)
+
+    @classmethod
+    def batch_exp(cls, ctx, curve, group, scalars) -> "Bases":
+        """P_i = s_i G (libff::batch_exp shape); scalars: ints or n x 32 B little-endian bytes."""
+        buf = scalars if isinstance(scalars, (bytes, bytearray)) else encode_scalars(scalars)
+        n = len(buf) // 32
+        h = ctypes.c_void_p()
+        _check(ctx._L.zg_bases_batch_exp(ctx._h, curve, group, bytes(buf), n, ctypes.byref(h)))
+        return cls(ctx, curve, group, h, n)
+
+    def read_bytes(self, first: int, count: int, form: int = FORM_PLAIN) -> bytes:
+        ab = affine_bytes(self.curve, self.group)
+        out = ctypes.create_string_buffer(max(1, count * ab))
+        _check(self._L.zg_bases_read(self._h, first, count, form, out))
+        return out.raw[: count * ab]
 
     def read(self, first: int, count: int) -> list:
         ab = affine_bytes(self.curve, self.group)
