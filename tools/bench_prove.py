@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Groth16 prove benchmark on the JoinSplit-shaped synthetic circuit (BASELINE.json configs[0]/[3] stand-in; NOT the
+Zeth circuit -- see zeth_amd/synth_circuit.py).  Real key from fixed secrets, fixed (r, s), proof compared bit for bit
+with the CPU oracle's on the same key and checked with the pairing verifier.  Prints one JSON line."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--curve", default="alt-bn128")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import zeth_amd
+    import zeth_amd.lib as zl
+    from zeth_amd.keygen import CURVE_INFO, generate_setup_from_secrets
+    from zeth_amd.synth_circuit import joinsplit_shaped
+
+    cid = 0 if args.curve == "alt-bn128" else 1
+    info = CURVE_INFO[cid]
+    t = time.time()
+    cs, primary, aux = joinsplit_shaped(info.r, seed=1, scale=args.scale)
+    t_circ = time.time() - t
+    ctx = zeth_amd.Context(0)
+    t = time.time()
+    dpk, vk, extra = generate_setup_from_secrets(ctx, cid, cs, t=0x5A4554485F746175, alpha=0x616C706861, beta=0x62657461,
+                                                 delta=0x64656C7461, return_scalars=not args.no_cpu)
+    t_key = time.time() - t
+    snark = zeth_amd.Groth16Snark(ctx, cid)
+    r_rand, s_rand = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321
+    n = zl.fq_bytes(cid)
+    pb = ctypes.create_string_buffer(zl.encode_scalars(primary), 32 * len(primary))
+    ab = ctypes.create_string_buffer(zl.encode_scalars(aux), 32 * len(aux))
+    out = ctypes.create_string_buffer(8 * n)
+    rb, sb = zl.int_to_le(r_rand, 32), zl.int_to_le(s_rand, 32)
+
+    def prove_once():
+        zl._check(ctx._L.zg_prove(dpk._h, pb, len(primary), ab, len(aux), zl.FORM_PLAIN, rb, sb, zl.FORM_PLAIN, out))
+
+    for _ in range(args.warmup):
+        prove_once()
+    ctx.synchronize()
+    times = []
+    for _ in range(args.steps):
+        t = time.perf_counter()
+        prove_once()
+        times.append(time.perf_counter() - t)
+    raw = out.raw
+    proof = (zl.decode_point(cid, 1, raw[: 2 * n]), zl.decode_point(cid, 2, raw[2 * n: 6 * n]), zl.decode_point(cid, 1, raw[6 * n:]))
+    times.sort()
+    res = {
+        "metric": "groth16_prove_joinsplit_shaped", "curve": args.curve,
+        "constraints": cs.num_constraints, "variables": cs.num_variables, "domain": cs.domain_size(),
+        "ms_per_proof_median": times[len(times) // 2] * 1e3, "ms_per_proof_min": times[0] * 1e3,
+        "proofs_per_s_per_gpu": 1.0 / times[len(times) // 2],
+        "timing": "assignment in host memory -> proof in host memory; key resident on device",
+        "setup_s": {"circuit": t_circ, "keygen": t_key},
+    }
+    if not args.no_cpu:
+        import cpu_oracle
+
+        threads = min(16, cpu_oracle.max_threads())
+        cpu_oracle.lib().oz_set_threads(threads)
+        keep = []
+
+        def vp(b):
+            cb = ctypes.create_string_buffer(b, max(1, len(b)))
+            keep.append(cb)
+            return ctypes.cast(cb, ctypes.c_void_p)
+
+        pl = extra["plain"]
+        pts = extra["points"]
+        views = []
+        for k in range(3):
+            vals = b"".join(v.to_bytes(32, "little") for v in cs.val[k])
+            views.append(cpu_oracle.CsrView(cs.row_ptr[k].ctypes.data, cs.col[k].ctypes.data, vp(vals)))
+        views = (cpu_oracle.CsrView * 3)(*views)
+        import numpy as np
+
+        bidx = np.array(extra["b_idx"], dtype=np.uint32)
+        enc = lambda g, P: vp(cpu_oracle.enc_point(cid, g, P))  # noqa: E731
+        view = cpu_oracle.PkView(enc(1, pts[0]), enc(1, pts[1]), enc(2, pts[2]), enc(1, pts[3]), enc(2, pts[4]),
+                                 vp(pl["A"]), cs.num_variables + 1, bidx.ctypes.data, vp(pl["B2"]), vp(pl["B1"]), len(bidx),
+                                 vp(pl["H"]), cs.domain_size() - 1, vp(pl["L"]), cs.num_variables - cs.num_inputs)
+        full = vp(zl.encode_scalars(primary) + zl.encode_scalars(aux))
+        cout = ctypes.create_string_buffer(8 * n)
+        sec = (ctypes.c_double * 3)()
+        rc = cpu_oracle.lib().oz_prove(cid, ctypes.byref(view), cs.num_inputs, cs.num_variables, cs.num_constraints, views,
+                                       full, rb, sb, threads, cout, sec)
+        assert rc == 0
+        res["bit_exact_vs_cpu_oracle"] = cout.raw == raw
+        res["cpu_baseline"] = {"ms_per_proof": sec[2] * 1e3, "witness_map_ms": sec[0] * 1e3, "msm_ms": sec[1] * 1e3,
+                               "cores": threads, "kind": "port",
+                               "note": "C++ restatement of the libsnark prover (BDLO12 multi_exp with 0/1 filter, OpenMP)"}
+        res["speedup_vs_cpu"] = sec[2] / times[len(times) // 2]
+    if not args.no_verify:
+        from zeth_model import BLS12_377, BN254, VerificationKey, verify
+
+        C = BN254 if cid == 0 else BLS12_377
+        mvk = VerificationKey()
+        mvk.alpha_g1, mvk.beta_g2, mvk.delta_g2, mvk.ABC_g1 = vk.alpha_g1, vk.beta_g2, vk.delta_g2, vk.ABC_g1
+        res["verifies"] = bool(verify(C, mvk, primary, proof))
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
