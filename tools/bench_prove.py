@@ -37,7 +37,7 @@ def main():
     ctx = zeth_amd.Context(0)
     t = time.time()
     dpk, vk, extra = generate_setup_from_secrets(ctx, cid, cs, t=0x5A4554485F746175, alpha=0x616C706861, beta=0x62657461,
-                                                 delta=0x64656C7461, return_scalars=not args.no_cpu)
+                                                 delta=0x64656C7461, return_scalars=True)
     t_key = time.time() - t
     snark = zeth_amd.Groth16Snark(ctx, cid)
     r_rand, s_rand = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321

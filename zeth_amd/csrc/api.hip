@@ -65,6 +65,7 @@ void zg_ctx_destroy(zg_ctx* c) {
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   for (auto& kv : c->ntt_domains) delete kv.second;
   if (c->ws) hipFree(c->ws);
+  if (c->pinned) hipHostFree(c->pinned);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }

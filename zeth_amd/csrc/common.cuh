@@ -36,6 +36,21 @@ struct zg_ctx {
   // grow-only workspace, bump-allocated per call
   char* ws = nullptr;
   size_t ws_cap = 0, ws_used = 0;
+  // pinned host staging for asynchronous result copies + the MSM job in flight on this context
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  size_t job_n = 0;
+  int job_W = 0, job_c = 0;
+  int pinned_reserve(size_t bytes) {
+    if (bytes <= pinned_cap) return ZG_OK;
+    if (pinned) ZG_HIP(hipHostFree(pinned));
+    pinned = nullptr;
+    pinned_cap = 0;
+    size_t want = bytes < 65536 ? 65536 : bytes;
+    ZG_HIP(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+    pinned_cap = want;
+    return ZG_OK;
+  }
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -102,6 +117,9 @@ struct GroupOps {
   // d_pts: device affine points (Montgomery).  d_scalars: device Fr elements.
   int (*msm)(zg_ctx*, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
              int out_form, void* out_affine_host);
+  // the same split in two: queue on the context's stream / wait + host tail (contexts run concurrently)
+  int (*msm_launch)(zg_ctx*, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c);
+  int (*msm_finish)(zg_ctx*, int out_form, void* out_affine_host);
   int (*to_mont)(zg_ctx*, void* d_pts, size_t n);  // plain -> Montgomery in place
   int (*generate)(zg_ctx*, void* d_pts, size_t n, const uint32_t* t0, const uint32_t* d);
   int (*batch_exp)(zg_ctx*, void* d_pts, size_t n, const uint32_t* d_scalars_plain);

@@ -144,12 +144,18 @@ int host_group_op(int op, const void* a, const void* b, int form, void* out) {
 // ---------------------------------------------------------------------------------------------
 // MSM driver
 // ---------------------------------------------------------------------------------------------
-// Runs the device pipeline and leaves the W window sums in host memory `win` (size >= plan.W).
+// Queues the device pipeline on ctx's stream; the W window sums land in ctx->pinned (asynchronous copy).
+// msm_finish() waits for them and runs the host tail.  Several contexts ("lanes") can be in flight at once.
 template <class F, class Fr>
-int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars, size_t n, int scalars_mont,
-               int force_c, MsmPlan& plan, std::vector<XYZZ<F>>& win) {
-  plan = msm_make_plan(n, Fr::Params::BITS, force_c);
+int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c) {
+  ctx->job_n = n;
+  if (n == 0) return ZG_OK;
+  const Affine<F>* d_bases = reinterpret_cast<const Affine<F>*>(d_pts);
+  const MsmPlan plan = msm_make_plan(n, Fr::Params::BITS, force_c);
   const MsmPlan& p = plan;
+  ctx->job_W = p.W;
+  ctx->job_c = p.c;
+  ZG_TRY(ctx->pinned_reserve((size_t)p.W * sizeof(XYZZ<F>)));
   if ((uint64_t)p.W * (uint64_t)n >= (1ull << 32)) return ZG_ERR_UNSUPPORTED;
   const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
   size_t need = zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
@@ -206,29 +212,30 @@ int msm_device(zg_ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars,
   hipLaunchKernelGGL((k_reduce2<F>), dim3(p.W), dim3(p.T), 0, st, seg, p.T);
   ctx->mark("end");
   ZG_HIP(hipGetLastError());
-  win.resize(p.W);
-  // gather the W window sums (strided by T) with one 2D copy
-  ZG_HIP(hipMemcpy2DAsync(win.data(), sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), p.W,
+  // gather the W window sums (strided by T) with one 2D copy into pinned host memory
+  ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), p.W,
                           hipMemcpyDeviceToHost, st));
-  ZG_HIP(hipStreamSynchronize(st));
-  ctx->prof_end();
+  return ZG_OK;
+}
+
+template <class F>
+int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
+  Affine<F> res = Affine<F>::inf();
+  if (ctx->job_n > 0) {
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->prof_end();
+    res = xyzz_to_affine(host_horner(reinterpret_cast<const XYZZ<F>*>(ctx->pinned), ctx->job_W, ctx->job_c));
+  }
+  if (out_form == ZG_FORM_PLAIN) host_affine_convert(&res, 1, 0);
+  memcpy(out_affine_host, &res, sizeof(res));
   return ZG_OK;
 }
 
 template <class F, class Fr>
 int msm_run(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
             int out_form, void* out_affine_host) {
-  Affine<F> res = Affine<F>::inf();
-  if (n > 0) {
-    MsmPlan plan;
-    std::vector<XYZZ<F>> win;
-    ZG_TRY((msm_device<F, Fr>(ctx, reinterpret_cast<const Affine<F>*>(d_pts), d_scalars, n, scalars_mont, force_c,
-                              plan, win)));
-    res = xyzz_to_affine(host_horner(win.data(), plan.W, plan.c));
-  }
-  if (out_form == ZG_FORM_PLAIN) host_affine_convert(&res, 1, 0);
-  memcpy(out_affine_host, &res, sizeof(res));
-  return ZG_OK;
+  ZG_TRY((msm_launch<F, Fr>(ctx, d_pts, d_scalars, n, scalars_mont, force_c)));
+  return msm_finish<F>(ctx, out_form, out_affine_host);
 }
 
 template <class F>
@@ -326,6 +333,8 @@ struct G2Gen {
                                 (size_t)zg::BaseField<F>::type::N,                                \
                                 (int)(sizeof(zg::Affine<F>) / sizeof(zg::BaseField<F>::type)),    \
                                 &zg::msm_run<F, FR>,                                              \
+                                &zg::msm_launch<F, FR>,                                           \
+                                &zg::msm_finish<F>,                                               \
                                 &zg::bases_to_mont<F>,                                            \
                                 &zg::bases_generate<F, FR, GEN>,                                  \
                                 &zg::bases_batch_exp<F, FR, GEN>,                                 \

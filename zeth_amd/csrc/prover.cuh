@@ -53,7 +53,15 @@ __global__ void __launch_bounds__(256) k_spmv(const uint64_t* __restrict__ row_p
   if (i >= m) return;
   Fr acc = Fr::zero();
   if (i < nc) {
-    for (uint64_t t = row_ptr[i]; t < row_ptr[i + 1]; t++) acc = Fr::add(acc, Fr::mul(glob_get(val + t), glob_get(w + col[t])));
+    // most coefficients of a boolean-heavy circuit are +1 or -1: those terms need no multiplication
+    const Fr one = Fr::one(), minus_one = Fr::neg(Fr::one());
+    for (uint64_t t = row_ptr[i]; t < row_ptr[i + 1]; t++) {
+      const Fr v = glob_get(val + t);
+      const Fr x = glob_get(w + col[t]);
+      if (v == one) acc = Fr::add(acc, x);
+      else if (v == minus_one) acc = Fr::sub(acc, x);
+      else acc = Fr::add(acc, Fr::mul(v, x));
+    }
   } else if (i - nc < extra_rows) {
     acc = glob_get(w + (i - nc));
   }
@@ -93,10 +101,15 @@ struct ProvingKeyDev : PkBase {
   // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
   Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
   Fr z_inv;
+  zg_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t w_ready = nullptr;
 
   ~ProvingKeyDev() override {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (auto& l : lane)
+      if (l) zg_ctx_destroy(l);
+    if (w_ready) hipEventDestroy(w_ready);
     for (auto& M : mat) {
       hipFree(M.row_ptr);
       hipFree(M.col);
@@ -184,6 +197,8 @@ struct ProvingKeyDev : PkBase {
       host_affine_convert(&beta_g2, 1, 1);
       host_affine_convert(&delta_g2, 1, 1);
     }
+    for (auto& l : lane) ZG_TRY(zg_ctx_create(ctx->device, &l));
+    ZG_HIP(hipEventCreateWithFlags(&w_ready, hipEventDisableTiming));
     ZG_HIP(hipMalloc((void**)&w, (num_vars + 1) * sizeof(Fr)));
     for (int k = 0; k < 3; k++) ZG_HIP(hipMalloc((void**)&ev[k], m * sizeof(Fr)));
     ZG_HIP(hipMalloc((void**)&tmp, m * sizeof(Fr)));
@@ -203,14 +218,24 @@ struct ProvingKeyDev : PkBase {
   // leaves the m + 1 coefficients of H (Montgomery; entry m is zero by construction and not stored) in `tmp`
   // and 1||w in `w`
   int witness_map(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form) {
+    ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
+    return qap_h();
+  }
+
+  // 1 || w in Montgomery form on the device
+  int load_assignment(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form) {
     if (n_primary != num_inputs || n_primary + n_aux != num_vars) return ZG_ERR_INVALID_ARGUMENT;
     hipStream_t st = ctx->stream;
-    ctx->mark("upload");
     if (n_primary) ZG_HIP(hipMemcpyAsync(assign, primary, n_primary * sizeof(Fr), hipMemcpyHostToDevice, st));
     if (n_aux) ZG_HIP(hipMemcpyAsync(assign + n_primary, aux, n_aux * sizeof(Fr), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((k_build_w<Fr>), dim3((unsigned)((num_vars + 1 + 255) / 256)), dim3(256), 0, st, assign, n_primary,
                        assign + n_primary, n_aux, form == ZG_FORM_PLAIN, w);
-    ctx->mark("spmv");
+    return ZG_OK;
+  }
+
+  // constraint evaluation, the seven transforms and the pointwise pass: H's coefficients end up in `tmp`
+  int qap_h() {
+    hipStream_t st = ctx->stream;
     const unsigned mb = (unsigned)((m + 255) / 256);
     for (int k = 0; k < 3; k++)
       hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb), dim3(256), 0, st, mat[k].row_ptr, mat[k].col, (const Fr*)mat[k].val, w, nc, m,
@@ -221,7 +246,6 @@ struct ProvingKeyDev : PkBase {
       ZG_TRY(ntt_launch<Fr>(ctx, D, ev[k], tmp, 1, 0));  // iFFT
       ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[k], 0, 1));  // cosetFFT
     }
-    ctx->mark("pointwise");
     hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
     ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
     ZG_HIP(hipGetLastError());
@@ -230,19 +254,29 @@ struct ProvingKeyDev : PkBase {
 
   int prove_impl(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
                  const uint32_t* r_plain, const uint32_t* s_plain, int out_form, void* proof_out) {
-    ZG_TRY(witness_map(primary, n_primary, aux, n_aux, form));
+    ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
     hipStream_t st = ctx->stream;
     if (B_len) hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
+    // The A, B (G2 and G1) and L evaluations depend only on 1||w: they run on four side streams ("lanes", each a
+    // context with its own workspace) while the main stream computes H's coefficients and then the H evaluation.
+    ZG_HIP(hipEventRecord(w_ready, st));
+    for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
     const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
     const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
     Affine<Fq> At, Bt1, Ht, Lt;
     Affine<Fq2T> Bt2;
     // scalars are Montgomery residues in device memory
-    ZG_TRY(o1->msm(ctx, A, (const uint32_t*)w, A_len, 1, 0, ZG_FORM_MONT, &At));
-    ZG_TRY(o2->msm(ctx, B2, (const uint32_t*)bsc, B_len, 1, 0, ZG_FORM_MONT, &Bt2));
-    ZG_TRY(o1->msm(ctx, B1, (const uint32_t*)bsc, B_len, 1, 0, ZG_FORM_MONT, &Bt1));
-    ZG_TRY(o1->msm(ctx, H, (const uint32_t*)tmp, H_len, 1, 0, ZG_FORM_MONT, &Ht));
-    ZG_TRY(o1->msm(ctx, L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, 0, ZG_FORM_MONT, &Lt));
+    ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, 0));
+    ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, 0));
+    ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, 0));
+    ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, 0));
+    ZG_TRY(qap_h());
+    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, 0));
+    ZG_TRY(o1->msm_finish(lane[1], ZG_FORM_MONT, &At));
+    ZG_TRY(o1->msm_finish(lane[2], ZG_FORM_MONT, &Lt));
+    ZG_TRY(o1->msm_finish(lane[3], ZG_FORM_MONT, &Bt1));
+    ZG_TRY(o2->msm_finish(lane[0], ZG_FORM_MONT, &Bt2));
+    ZG_TRY(o1->msm_finish(ctx, ZG_FORM_MONT, &Ht));
     // host tail
     auto X1 = [](const Affine<Fq>& p) { return XYZZ<Fq>::from_affine(p); };
     auto X2 = [](const Affine<Fq2T>& p) { return XYZZ<Fq2T>::from_affine(p); };

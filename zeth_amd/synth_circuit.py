@@ -50,7 +50,8 @@ def joinsplit_shaped(r: int, seed: int = 1, scale: float = 1.0):
         w[int(v_chain[k])] = s_prev
         prev_var = int(v_chain[k])
     # public input = last chain value + sum of the packed words (a stand-in for "hash of the public data")
-    w[1] = (s_prev + sum(w[int(v)] for v in v_pack.tolist())) % r
+    n_out = min(n_pack, 64)  # the public input binds the chain output and the first packed words
+    w[1] = (s_prev + sum(w[int(v)] for v in v_pack.tolist()[:n_out])) % r
 
     rows = [[], [], []]  # per matrix: list of (cols, vals)
     neg1 = r - 1
@@ -75,7 +76,7 @@ def joinsplit_shaped(r: int, seed: int = 1, scale: float = 1.0):
             acc[2 + j] = acc.get(2 + j, 0) + pw[i]
         cols = sorted(acc)
         add((cols, [acc[c] for c in cols]), ([0], [1]), ([int(v_pack[k])], [1]))
-    add(([prev_var] + [int(v) for v in v_pack.tolist()], [1] * (1 + n_pack)), ([0], [1]), ([1], [1]))
+    add(([prev_var] + [int(v) for v in v_pack.tolist()[:n_out]], [1] * (1 + n_out)), ([0], [1]), ([1], [1]))
     nc = len(rows[0])
     cs = CsrR1cs(1, nv, nc)
     for k in range(3):
