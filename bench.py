@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--cpu-log-n", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prove", action="store_true", help="skip the JoinSplit-shaped Groth16 prove measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +154,31 @@ def main():
         raise SystemExit("bench.py: MSM result does not match the closed form (rerun equal to first: %s, rerun correct: %s)"
                          % (again == result, again == expect))
 
+    cpu_base = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(bases, scalars, min(n_local, 1 << args.cpu_log_n))
+
+    # second headline number (BASELINE.json metric): Groth16 proofs/s on the JoinSplit-shaped circuit, every rank a
+    # replica with its own resident key (no collective); outside the timed MSM region above
+    prove = None
+    if not args.no_prove:
+        import types
+
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_prove
+
+        bases.free()
+        pargs = types.SimpleNamespace(curve="alt-bn128", scale=1.0, steps=10, warmup=2,
+                                      no_cpu=(rank != 0 or args.no_cpu_baseline), no_verify=(rank != 0))
+        prove = bench_prove.measure(pargs, ctx)
+        rate = prove["proofs_per_s_per_gpu"]
+        if world > 1:
+            tr = torch.tensor([rate], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+            rate = float(tr.item())
+        prove["proofs_per_s_node"] = rate
+        prove["n_gpus"] = world
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         k_ms = sum(accum_ms) / len(accum_ms)
@@ -194,8 +220,10 @@ def main():
             },
             "phases_ms": {k2: v / args.steps for k2, v in phase_ms.items()},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(bases, scalars, min(n_local, 1 << args.cpu_log_n))
+        if prove is not None:
+            out["joinsplit_prove"] = prove
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

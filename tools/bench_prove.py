@@ -23,7 +23,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
+    print(json.dumps(measure(args)), flush=True)
 
+
+def measure(args, ctx=None):
     import zeth_amd
     import zeth_amd.lib as zl
     from zeth_amd.keygen import CURVE_INFO, generate_setup_from_secrets
@@ -34,7 +37,8 @@ def main():
     t = time.time()
     cs, primary, aux = joinsplit_shaped(info.r, seed=1, scale=args.scale)
     t_circ = time.time() - t
-    ctx = zeth_amd.Context(0)
+    if ctx is None:
+        ctx = zeth_amd.Context(0)
     t = time.time()
     dpk, vk, extra = generate_setup_from_secrets(ctx, cid, cs, t=0x5A4554485F746175, alpha=0x616C706861, beta=0x62657461,
                                                  delta=0x64656C7461, return_scalars=True)
@@ -113,7 +117,8 @@ def main():
         mvk = VerificationKey()
         mvk.alpha_g1, mvk.beta_g2, mvk.delta_g2, mvk.ABC_g1 = vk.alpha_g1, vk.beta_g2, vk.delta_g2, vk.ABC_g1
         res["verifies"] = bool(verify(C, mvk, primary, proof))
-    print(json.dumps(res), flush=True)
+    dpk.free()
+    return res
 
 
 if __name__ == "__main__":

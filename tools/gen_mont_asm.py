@@ -57,8 +57,11 @@ def gen_mul(N):
     L.append("v_sub_co_u32 %s, vcc, %s, v%d" % (lo(0), t(0), P(0) + N))
     for j in range(1, N):
         L.append("v_subb_co_u32 v%d, vcc, %s, v%d, vcc" % (P(0) + j, t(j), P(0) + N + j))
+    # mask = borrow ? ~0 : 0 ; r = (t & mask) | (d & ~mask).  (v_cndmask_b32 on vcc measured ~20 cycles per wave
+    # instruction on gfx950 against 4 for v_bfi_b32: profiles/r1_peak_valu.jsonl)
+    L.append("v_subb_co_u32 v%d, vcc, 0, 0, vcc" % M)
     for j in range(N):
-        L.append("v_cndmask_b32 %s, v%d, %s, vcc" % (r(j), P(0) + j, t(j)))
+        L.append("v_bfi_b32 %s, v%d, %s, v%d" % (r(j), M, t(j), P(0) + j))
     clob = ", ".join('"v%d"' % k for k in range(TB, last + 1))
     outs = ", ".join('"=v"(r[%d])' % j for j in range(N))
     ins = ", ".join(['"v"(a[%d])' % j for j in range(N)] + ['"v"(b[%d])' % j for j in range(N)] +
@@ -93,9 +96,11 @@ def gen_addsub(N):
     L.append("v_sub_co_u32 %s, vcc, %s, %s" % (D(0), S(0), p(0)))
     for j in range(1, N):
         L.append("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (D(j), S(j), p(j)))
+    MK = "v%d" % (TB + 2 * N)
+    L.append("v_subb_co_u32 %s, vcc, 0, 0, vcc" % MK)
     for j in range(N):
-        L.append("v_cndmask_b32 %s, %s, %s, vcc" % (r(j), D(j), S(j)))
-    clob = ", ".join('"v%d"' % k for k in range(TB, TB + 2 * N))
+        L.append("v_bfi_b32 %s, %s, %s, %s" % (r(j), MK, S(j), D(j)))
+    clob = ", ".join('"v%d"' % k for k in range(TB, TB + 2 * N + 1))
     outs = ", ".join('"=v"(r[%d])' % j for j in range(N))
     ins = ", ".join(['"v"(a[%d])' % j for j in range(N)] + ['"v"(b[%d])' % j for j in range(N)] + ['"v"(p[%d])' % j for j in range(N)])
     body = "\n".join('      "%s\\n"' % s for s in L)
@@ -115,8 +120,9 @@ __device__ __forceinline__ void zg_mont_add_%d(uint32_t* __restrict__ r, const u
     for j in range(1, N):
         L.append("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (D(j), a(j), b(j)))
     # S(j) = borrow ? p_j : 0
+    L.append("v_subb_co_u32 %s, vcc, 0, 0, vcc" % MK)
     for j in range(N):
-        L.append("v_cndmask_b32 %s, 0, %s, vcc" % (S(j), p(j)))
+        L.append("v_and_b32 %s, %s, %s" % (S(j), MK, p(j)))
     L.append("v_add_co_u32 %s, vcc, %s, %s" % (r(0), D(0), S(0)))
     for j in range(1, N):
         L.append("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (r(j), D(j), S(j)))
@@ -133,6 +139,33 @@ __device__ __forceinline__ void zg_mont_sub_%d(uint32_t* __restrict__ r, const u
 #endif
 }
 """ % (N, body, outs_ec, ins, clob))
+    # cneg: r = (flagmask && a != 0) ? p - a : a      (flagmask: all-ones or zero)
+    L = ["v_sub_co_u32 %s, vcc, %s, %s" % (D(0), p(0), a(0))]
+    for j in range(1, N):
+        L.append("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (D(j), p(j), a(j)))
+    L.append("v_or_b32 %s, %s, %s" % (S(0), a(0), a(1)))
+    for j in range(2, N):
+        L.append("v_or_b32 %s, %s, %s" % (S(0), S(0), a(j)))
+    L.append("v_cmp_ne_u32 vcc, 0, %s" % S(0))
+    L.append("v_subb_co_u32 %s, vcc, 0, 0, vcc" % MK)  # all-ones when a != 0
+    L.append("v_and_b32 %s, %s, %%%d" % (MK, MK, 4 * N))
+    for j in range(N):
+        L.append("v_bfi_b32 %s, %s, %s, %s" % (r(j), MK, D(j), a(j)))
+    outs_ec = ", ".join('"=&v"(r[%d])' % j for j in range(N))
+    ins_c = ", ".join(['"v"(a[%d])' % j for j in range(N)] + ['"v"(a[%d])' % j for j in range(N)] +
+                      ['"v"(p[%d])' % j for j in range(N)] + ['"v"(flagmask)'])
+    body = "\n".join('      "%s\\n"' % s for s in L)
+    out.append("""
+__device__ __forceinline__ void zg_mont_cneg_%d(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* p, uint32_t flagmask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(
+%s
+      : %s
+      : %s
+      : "vcc", %s);
+#endif
+}
+""" % (N, body, outs_ec, ins_c, clob))
     return "".join(out)
 
 

@@ -143,6 +143,9 @@ struct Fp {
     return d;
   }
   ZG_HD static Fp neg(const Fp& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_ASM_FIELD
+    if constexpr (N == 8 || N == 12) return cneg(a, true);
+#endif
     Fp d;
     uint64_t br = 0;
     uint32_t nz = 0;
@@ -160,6 +163,18 @@ struct Fp {
   }
   // conditional negate (used for signed-digit bucket entries)
   ZG_HD static Fp cneg(const Fp& a, bool flag) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_ASM_FIELD
+    if constexpr (N == 8 || N == 12) {
+      uint32_t p[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) p[i] = P::P[i];
+      Fp r;
+      const uint32_t mask = flag ? 0xFFFFFFFFu : 0u;
+      if constexpr (N == 8) zg_mont_cneg_8(r.v, a.v, p, mask);
+      else zg_mont_cneg_12(r.v, a.v, p, mask);
+      return r;
+    }
+#endif
     Fp n = neg(a);
     Fp r;
 #pragma unroll
