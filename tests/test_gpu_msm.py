@@ -120,3 +120,27 @@ def test_msm_generated_bases_closed_form(ctx, curve, group, n):
     sab = [(a + b) % C.r for a, b in zip(sc, sb)]
     assert zeth_amd.host_group_op(cid, group, "add", bases.msm(sc), bases.msm(sb)) == bases.msm(sab)
     bases.free()
+
+
+@pytest.mark.parametrize("window_bits", [0, 10, 13, 16])
+def test_msm_skewed_scalars_two_level_sort(ctx, window_bits):
+    """0/1-heavy and tiny-valued scalars (the JoinSplit witness shape) at a size that takes the two-level sort and
+    the split-bucket tree: a few buckets hold almost every entry, most partitions are empty."""
+    import zeth_amd
+
+    C = BN254
+    rng = random.Random(4242 + window_bits)
+    n = 40000
+    t0, d = rng.randrange(C.r), rng.randrange(C.r)
+    bases = zeth_amd.Bases.generate(ctx, 0, 1, n, t0, d)
+    sc = []
+    for i in range(n):
+        u = rng.random()
+        sc.append(0 if u < 0.3 else 1 if u < 0.8 else C.r - 1 if u < 0.85 else rng.randrange(1 << 20) if u < 0.95 else rng.randrange(C.r))
+    k = sum(a * (t0 + i * d) for i, a in enumerate(sc)) % C.r
+    assert bases.msm(sc, window_bits=window_bits) == C.G1.mul(k, C.G1.gen)
+    # all scalars equal: every entry of a window lands in one bucket
+    same = [0x123456789ABCDEF] * n
+    k = sum(a * (t0 + i * d) for i, a in enumerate(same)) % C.r
+    assert bases.msm(same, window_bits=window_bits) == C.G1.mul(k, C.G1.gen)
+    bases.free()

@@ -160,9 +160,10 @@ ZG_HD_COLD XYZZ<F> xyzz_mul_limbs(const XYZZ<F>& a, const uint32_t* k, int nlimb
 template <class F>
 ZG_HD_COLD Affine<F> xyzz_to_affine(const XYZZ<F>& a) {
   if (a.is_inf()) return Affine<F>::inf();
-  // 1/zzz, then 1/zz = zzz^-1 * (zzz/zz) ... two inversions kept simple: the tail runs O(1) times
+  // one inversion: zz^3 = zzz^2, so 1/z = zz / zzz and 1/zz = (1/z)^2
   F izzz = F::inv(a.zzz);
-  F izz = F::inv(a.zz);
+  F iz = F::mul(a.zz, izzz);
+  F izz = F::sqr(iz);
   return Affine<F>{F::mul(a.x, izz), F::mul(a.y, izzz)};
 }
 

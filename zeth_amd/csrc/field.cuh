@@ -194,6 +194,48 @@ struct Fp {
       return r;
     }
 #endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host tail: the same Montgomery product (same R = 2^(32 N)) on 64-bit limbs with unsigned __int128
+    if constexpr (N % 2 == 0) {
+      constexpr int M = N / 2;
+      typedef unsigned __int128 u128;
+      uint64_t A[M], B[M], Pm[M], t64[M + 2];
+      for (int i = 0; i < M; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+        Pm[i] = (uint64_t)P::P[2 * i] | ((uint64_t)P::P[2 * i + 1] << 32);
+      }
+      for (int i = 0; i < M + 2; i++) t64[i] = 0;
+      for (int i = 0; i < M; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < M; j++) {
+          u128 x = (u128)A[j] * B[i] + t64[j] + carry;
+          t64[j] = (uint64_t)x;
+          carry = (uint64_t)(x >> 64);
+        }
+        u128 x = (u128)t64[M] + carry;
+        t64[M] = (uint64_t)x;
+        t64[M + 1] = (uint64_t)(x >> 64);
+        const uint64_t m = t64[0] * P::INV64;
+        x = (u128)m * Pm[0] + t64[0];
+        carry = (uint64_t)(x >> 64);
+        for (int j = 1; j < M; j++) {
+          x = (u128)m * Pm[j] + t64[j] + carry;
+          t64[j - 1] = (uint64_t)x;
+          carry = (uint64_t)(x >> 64);
+        }
+        x = (u128)t64[M] + carry;
+        t64[M - 1] = (uint64_t)x;
+        t64[M] = t64[M + 1] + (uint64_t)(x >> 64);
+      }
+      Fp r;
+      for (int i = 0; i < M; i++) {
+        r.v[2 * i] = (uint32_t)t64[i];
+        r.v[2 * i + 1] = (uint32_t)(t64[i] >> 32);
+      }
+      return reduce_once(r);  // t < 2p < R, so t64[M] == 0
+    }
+#endif
     uint32_t t[N];
 #pragma unroll
     for (int i = 0; i < N; i++) t[i] = 0;

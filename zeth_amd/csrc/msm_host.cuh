@@ -156,9 +156,11 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->job_W = p.W;
   ctx->job_c = p.c;
   ZG_TRY(ctx->pinned_reserve((size_t)p.W * sizeof(XYZZ<F>)));
-  if ((uint64_t)p.W * (uint64_t)n >= (1ull << 32)) return ZG_ERR_UNSUPPORTED;
+  if ((uint64_t)p.W * (uint64_t)n >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 32-bit entry positions with headroom
   const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
-  size_t need = zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
+  const uint32_t nhi = p.nb >= 512 ? (p.nb >> 8) : 0;  // two-level sort when a window has >= 512 buckets
+  size_t need = (nhi ? zg_ctx::ws_round(WN * 4) + zg_ctx::ws_round(WN) + 2 * zg_ctx::ws_round((size_t)p.W * (nhi + 1) * 4) : 0) +
+                zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
                 zg_ctx::ws_round((p.W + 1) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
   ZG_TRY(ctx->ws_reserve(need));
@@ -172,6 +174,15 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
   XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)p.W * p.T);
+  uint32_t *mid_ent = nullptr, *cursor1 = nullptr, *pstart = nullptr;
+  uint8_t* mid_lo = nullptr;
+  if (nhi) {
+    mid_ent = ctx->ws_take<uint32_t>(WN);
+    mid_lo = ctx->ws_take<uint8_t>(WN);
+    cursor1 = ctx->ws_take<uint32_t>((size_t)p.W * (nhi + 1));
+    pstart = ctx->ws_take<uint32_t>((size_t)p.W * (nhi + 1));
+    if (!mid_ent || !mid_lo || !cursor1 || !pstart) return ZG_ERR_OUT_OF_MEMORY;
+  }
   if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !wunits || !units || !part || !seg)
     return ZG_ERR_OUT_OF_MEMORY;
 
@@ -192,9 +203,20 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->mark("hist");
   hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
   ctx->mark("scan");
-  hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits);
+  hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits, nhi,
+                     cursor1, pstart);
   ctx->mark("scatter");
-  hipLaunchKernelGGL(k_scatter, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cursor, sorted);
+  if (nhi) {
+    hipLaunchKernelGGL(k_scatter_hi, dim3((unsigned)((n + SORT_TILE1 - 1) / SORT_TILE1), p.W), dim3(1024), 0, st, dig, n,
+                       nhi, cursor1, mid_ent, mid_lo);
+    size_t tiles = (2 * n / nhi + SORT_TILE2 - 1) / SORT_TILE2;
+    if (tiles < 1) tiles = 1;
+    if (tiles > 64) tiles = 64;
+    hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, p.W), dim3(1024), 0, st, mid_ent, mid_lo, pstart, nhi, p.nb,
+                       cursor, sorted);
+  } else {
+    hipLaunchKernelGGL(k_scatter, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cursor, sorted);
+  }
   ctx->mark("units");
   hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, p.nb,
                      (uint32_t)p.W, p.L, units);
@@ -218,14 +240,22 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   return ZG_OK;
 }
 
+static constexpr int ZG_FORM_XYZZ_INTERNAL = 2;  // msm_finish only: leave the sum as an XYZZ point (Montgomery)
+
 template <class F>
 int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
   Affine<F> res = Affine<F>::inf();
+  XYZZ<F> acc = XYZZ<F>::inf();
   if (ctx->job_n > 0) {
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof_end();
-    res = xyzz_to_affine(host_horner(reinterpret_cast<const XYZZ<F>*>(ctx->pinned), ctx->job_W, ctx->job_c));
+    acc = host_horner(reinterpret_cast<const XYZZ<F>*>(ctx->pinned), ctx->job_W, ctx->job_c);
   }
+  if (out_form == ZG_FORM_XYZZ_INTERNAL) {
+    memcpy(out_affine_host, &acc, sizeof(acc));
+    return ZG_OK;
+  }
+  res = xyzz_to_affine(acc);
   if (out_form == ZG_FORM_PLAIN) host_affine_convert(&res, 1, 0);
   memcpy(out_affine_host, &res, sizeof(res));
   return ZG_OK;

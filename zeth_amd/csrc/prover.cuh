@@ -263,8 +263,8 @@ struct ProvingKeyDev : PkBase {
     for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
     const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
     const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
-    Affine<Fq> At, Bt1, Ht, Lt;
-    Affine<Fq2T> Bt2;
+    XYZZ<Fq> At, Bt1, Ht, Lt;
+    XYZZ<Fq2T> Bt2;
     // scalars are Montgomery residues in device memory
     ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, 0));
     ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, 0));
@@ -272,32 +272,39 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, 0));
     ZG_TRY(qap_h());
     ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, 0));
-    ZG_TRY(o1->msm_finish(lane[1], ZG_FORM_MONT, &At));
-    ZG_TRY(o1->msm_finish(lane[2], ZG_FORM_MONT, &Lt));
-    ZG_TRY(o1->msm_finish(lane[3], ZG_FORM_MONT, &Bt1));
-    ZG_TRY(o2->msm_finish(lane[0], ZG_FORM_MONT, &Bt2));
-    ZG_TRY(o1->msm_finish(ctx, ZG_FORM_MONT, &Ht));
-    // host tail
+    // Host tail, ordered so that everything that does not need a device result runs while the GPU is busy:
+    // the four blinding multiples of delta first, then each evaluation as its lane completes.
     auto X1 = [](const Affine<Fq>& p) { return XYZZ<Fq>::from_affine(p); };
     auto X2 = [](const Affine<Fq2T>& p) { return XYZZ<Fq2T>::from_affine(p); };
-    XYZZ<Fq> gA = X1(alpha_g1);
-    xyzz_madd(gA, At);
-    xyzz_add(gA, xyzz_mul_limbs(X1(delta_g1), r_plain, Fr::N));
-    XYZZ<Fq> g1B = X1(beta_g1);
-    xyzz_madd(g1B, Bt1);
-    xyzz_add(g1B, xyzz_mul_limbs(X1(delta_g1), s_plain, Fr::N));
-    XYZZ<Fq2T> gB = X2(beta_g2);
-    xyzz_madd(gB, Bt2);
-    xyzz_add(gB, xyzz_mul_limbs(X2(delta_g2), s_plain, Fr::N));
     Fr rf, sf;
     memcpy(&rf, r_plain, sizeof(rf));
     memcpy(&sf, s_plain, sizeof(sf));
-    Fr rs = Fr::from_mont(Fr::mul(Fr::to_mont(rf), Fr::to_mont(sf)));
-    XYZZ<Fq> gC = X1(Ht);
-    xyzz_madd(gC, Lt);
-    xyzz_add(gC, xyzz_mul_limbs(gA, s_plain, Fr::N));
-    xyzz_add(gC, xyzz_mul_limbs(g1B, r_plain, Fr::N));
-    xyzz_add(gC, xyzz_neg(xyzz_mul_limbs(X1(delta_g1), rs.v, Fr::N)));
+    const Fr rs = Fr::from_mont(Fr::mul(Fr::to_mont(rf), Fr::to_mont(sf)));
+    const XYZZ<Fq> r_delta1 = xyzz_mul_limbs(X1(delta_g1), r_plain, Fr::N);
+    const XYZZ<Fq> s_delta1 = xyzz_mul_limbs(X1(delta_g1), s_plain, Fr::N);
+    const XYZZ<Fq> rs_delta1 = xyzz_mul_limbs(X1(delta_g1), rs.v, Fr::N);
+    const XYZZ<Fq2T> s_delta2 = xyzz_mul_limbs(X2(delta_g2), s_plain, Fr::N);
+    ZG_TRY(o1->msm_finish(lane[1], ZG_FORM_XYZZ_INTERNAL, &At));
+    XYZZ<Fq> gA = X1(alpha_g1);
+    xyzz_add(gA, At);
+    xyzz_add(gA, r_delta1);
+    const XYZZ<Fq> s_gA = xyzz_mul_limbs(gA, s_plain, Fr::N);
+    ZG_TRY(o1->msm_finish(lane[3], ZG_FORM_XYZZ_INTERNAL, &Bt1));
+    XYZZ<Fq> g1B = X1(beta_g1);
+    xyzz_add(g1B, Bt1);
+    xyzz_add(g1B, s_delta1);
+    const XYZZ<Fq> r_g1B = xyzz_mul_limbs(g1B, r_plain, Fr::N);
+    ZG_TRY(o2->msm_finish(lane[0], ZG_FORM_XYZZ_INTERNAL, &Bt2));
+    XYZZ<Fq2T> gB = X2(beta_g2);
+    xyzz_add(gB, Bt2);
+    xyzz_add(gB, s_delta2);
+    ZG_TRY(o1->msm_finish(lane[2], ZG_FORM_XYZZ_INTERNAL, &Lt));
+    ZG_TRY(o1->msm_finish(ctx, ZG_FORM_XYZZ_INTERNAL, &Ht));
+    XYZZ<Fq> gC = Ht;
+    xyzz_add(gC, Lt);
+    xyzz_add(gC, s_gA);
+    xyzz_add(gC, r_g1B);
+    xyzz_add(gC, xyzz_neg(rs_delta1));
     struct {
       Affine<Fq> a;
       Affine<Fq2T> b;
