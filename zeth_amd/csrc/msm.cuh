@@ -59,7 +59,13 @@ inline int ilog2_floor(size_t n) {
 inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   MsmPlan p{};
   p.n = n;
-  int c = ilog2_floor(n ? n : 1) - 4;
+  // window width tuned on MI355X (tools/tune_c.py): odd widths keep the per-window reduction short
+  int lg = ilog2_floor(n ? n : 1) + ((n & (n - 1)) ? 1 : 0);
+  int c;
+  if (lg <= 12) c = lg - 3;
+  else if (lg <= 16) c = 13;
+  else if (lg <= 20) c = 15;
+  else c = 16;
   if (c < 6) c = 6;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
   if (force_c) c = force_c;
@@ -419,7 +425,7 @@ __global__ void __launch_bounds__(256, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDes
 // Buckets that were split into several units (skewed scalars: 0/1-heavy witnesses, short top windows) are
 // folded by a pairwise tree, one launch per level: part[u0 + i] += part[u0 + i + s] for i % 2s == 0.
 template <class F>
-__global__ void __launch_bounds__(256) k_combine(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
+__global__ void __launch_bounds__(1024) k_combine(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
                                                   uint32_t W, uint32_t cap, const uint32_t* __restrict__ cnt,
                                                   const uint32_t* __restrict__ ufirst, uint32_t L, uint32_t s,
                                                   XYZZ<F>* __restrict__ part) {
@@ -473,6 +479,13 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
 template <class F>
 __global__ void __launch_bounds__(1024) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
   XYZZ<F>* s = seg + (size_t)blockIdx.x * T;
+  if (T > blockDim.x) {  // fold the tail onto the first blockDim entries
+    XYZZ<F> a = s[threadIdx.x];
+    for (uint32_t j = threadIdx.x + blockDim.x; j < T; j += blockDim.x) xyzz_add(a, s[j]);
+    s[threadIdx.x] = a;
+    __syncthreads();
+    T = blockDim.x;
+  }
   for (uint32_t h = T >> 1; h >= 1; h >>= 1) {
     if (threadIdx.x < h) {
       XYZZ<F> a = s[threadIdx.x];

@@ -225,13 +225,13 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                      d_bases, part);
   ctx->mark("combine");
   for (uint32_t s = 1; s < (uint32_t)((n + p.L - 1) / p.L); s <<= 1)
-    hipLaunchKernelGGL((k_combine<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
+    hipLaunchKernelGGL((k_combine<F>), dim3((p.cap + 1023) / 1024, p.W), dim3(1024), 0, st, units, wunits, (uint32_t)p.W,
                        p.cap, cnt, ufirst, p.L, s, part);
   ctx->mark("reduce1");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
                      p.k, p.L, (uint32_t)p.W, seg);
   ctx->mark("reduce2");
-  hipLaunchKernelGGL((k_reduce2<F>), dim3(p.W), dim3(p.T), 0, st, seg, p.T);
+  hipLaunchKernelGGL((k_reduce2<F>), dim3(p.W), dim3(p.T < 1024 ? p.T : 1024), 0, st, seg, p.T);
   ctx->mark("end");
   ZG_HIP(hipGetLastError());
   // gather the W window sums (strided by T) with one 2D copy into pinned host memory

@@ -11,7 +11,10 @@
 // An unsatisfied assignment is not an error: like the reference's release build it yields a proof that fails
 // verification (libzeth/tests/prover/prover_test.cpp:703-714).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include "msm_host.cuh"
 #include "ntt_host.cuh"
@@ -254,7 +257,13 @@ struct ProvingKeyDev : PkBase {
 
   int prove_impl(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
                  const uint32_t* r_plain, const uint32_t* s_plain, int out_form, void* proof_out) {
+    const bool trace = getenv("ZG_PROVE_TRACE") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+      if (trace) fprintf(stderr, "  [prove] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
     ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
+    stamp("assignment queued");
     hipStream_t st = ctx->stream;
     if (B_len) hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
     // The A, B (G2 and G1) and L evaluations depend only on 1||w: they run on four side streams ("lanes", each a
@@ -272,6 +281,7 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, 0));
     ZG_TRY(qap_h());
     ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, 0));
+    stamp("all work queued");
     // Host tail, ordered so that everything that does not need a device result runs while the GPU is busy:
     // the four blinding multiples of delta first, then each evaluation as its lane completes.
     auto X1 = [](const Affine<Fq>& p) { return XYZZ<Fq>::from_affine(p); };
@@ -284,22 +294,30 @@ struct ProvingKeyDev : PkBase {
     const XYZZ<Fq> s_delta1 = xyzz_mul_limbs(X1(delta_g1), s_plain, Fr::N);
     const XYZZ<Fq> rs_delta1 = xyzz_mul_limbs(X1(delta_g1), rs.v, Fr::N);
     const XYZZ<Fq2T> s_delta2 = xyzz_mul_limbs(X2(delta_g2), s_plain, Fr::N);
+    stamp("delta multiples (host)");
     ZG_TRY(o1->msm_finish(lane[1], ZG_FORM_XYZZ_INTERNAL, &At));
+    stamp("A finished");
     XYZZ<Fq> gA = X1(alpha_g1);
     xyzz_add(gA, At);
     xyzz_add(gA, r_delta1);
     const XYZZ<Fq> s_gA = xyzz_mul_limbs(gA, s_plain, Fr::N);
+    stamp("s*gA (host)");
     ZG_TRY(o1->msm_finish(lane[3], ZG_FORM_XYZZ_INTERNAL, &Bt1));
+    stamp("B1 finished");
     XYZZ<Fq> g1B = X1(beta_g1);
     xyzz_add(g1B, Bt1);
     xyzz_add(g1B, s_delta1);
     const XYZZ<Fq> r_g1B = xyzz_mul_limbs(g1B, r_plain, Fr::N);
+    stamp("r*g1B (host)");
     ZG_TRY(o2->msm_finish(lane[0], ZG_FORM_XYZZ_INTERNAL, &Bt2));
+    stamp("B2 finished");
     XYZZ<Fq2T> gB = X2(beta_g2);
     xyzz_add(gB, Bt2);
     xyzz_add(gB, s_delta2);
     ZG_TRY(o1->msm_finish(lane[2], ZG_FORM_XYZZ_INTERNAL, &Lt));
+    stamp("L finished");
     ZG_TRY(o1->msm_finish(ctx, ZG_FORM_XYZZ_INTERNAL, &Ht));
+    stamp("H finished");
     XYZZ<Fq> gC = Ht;
     xyzz_add(gC, Lt);
     xyzz_add(gC, s_gA);
@@ -319,6 +337,7 @@ struct ProvingKeyDev : PkBase {
       host_affine_convert(&proof.c, 1, 0);
     }
     memcpy(proof_out, &proof, sizeof(proof));
+    stamp("proof normalised");
     return ZG_OK;
   }
 
