@@ -39,7 +39,12 @@ int zg_sizes(int curve, size_t* fr, size_t* fq, size_t* g1, size_t* g2) {
   return ZG_OK;
 }
 
-int zg_ctx_create(int device, zg_ctx** out) {
+int zg_ctx_create(int device, zg_ctx** out) { return zg_ctx_create_prio(device, +1, out); }
+
+}  // extern "C"
+
+// prio > 0: highest stream priority (a context's main stream: the latency-critical chain), prio < 0: lowest (side lanes)
+int zg_ctx_create_prio(int device, int prio, zg_ctx** out) {
   if (!out) return ZG_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   int count = 0;
@@ -49,7 +54,9 @@ int zg_ctx_create(int device, zg_ctx** out) {
   zg_ctx* c = new (std::nothrow) zg_ctx();
   if (!c) return ZG_ERR_OUT_OF_MEMORY;
   c->device = device;
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+  hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio > 0 ? greatest : least);
   if (e != hipSuccess) {
     delete c;
     return ZG_ERR_HIP;
@@ -57,6 +64,8 @@ int zg_ctx_create(int device, zg_ctx** out) {
   *out = c;
   return ZG_OK;
 }
+
+extern "C" {
 
 void zg_ctx_destroy(zg_ctx* c) {
   if (!c) return;

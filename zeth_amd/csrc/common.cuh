@@ -41,6 +41,8 @@ struct zg_ctx {
   size_t pinned_cap = 0;
   size_t job_n = 0;
   int job_W = 0, job_c = 0;
+  bool want_dense = false;  // count scalars other than 0/1 during recoding (prover lanes)
+  uint32_t job_dense = 0;  // scalars other than 0/1 seen by the last MSM on this context
   int pinned_reserve(size_t bytes) {
     if (bytes <= pinned_cap) return ZG_OK;
     if (pinned) ZG_HIP(hipHostFree(pinned));
@@ -129,6 +131,7 @@ struct GroupOps {
 };
 
 const GroupOps* zg_group_ops(int curve, int group);
+int zg_ctx_create_prio(int device, int prio, zg_ctx** out);
 
 struct PkBase {
   virtual ~PkBase() {}

@@ -56,10 +56,9 @@ inline int ilog2_floor(size_t n) {
   return l;
 }
 
-inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
-  MsmPlan p{};
-  p.n = n;
-  // window width tuned on MI355X (tools/tune_c.py): odd widths keep the per-window reduction short
+// window width for n scalars that are not 0 or 1, tuned on MI355X (tools/tune_c.py): odd widths keep the
+// per-window reduction short
+inline int msm_pick_c(size_t n) {
   int lg = ilog2_floor(n ? n : 1) + ((n & (n - 1)) ? 1 : 0);
   int c;
   if (lg <= 12) c = lg - 3;
@@ -68,14 +67,24 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   else c = 16;
   if (c < 6) c = 6;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
+  return c;
+}
+
+inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
+  MsmPlan p{};
+  p.n = n;
+  int c = msm_pick_c(n);
   if (force_c) c = force_c;
   p.c = c;
   // need W*c >= scalar_bits + 2 so that s + K never overflows W windows
   p.W = (scalar_bits + 2 + c - 1) / c;
   p.nb = 1u << (c - 1);
-  size_t avg = n / p.nb;
-  size_t L = 2 * avg;
+  // Unit length: long enough that the pairwise combine tree stays small next to the accumulation, short enough
+  // that (i) at least about 2^18 units are in flight and (ii) one lane's chain of dependent mixed additions (~4.5 us each
+  // when a wave runs alone) does not set the kernel's duration when a few buckets hold most entries.
+  size_t L = ((size_t)p.W * n) >> 18;
   if (L < 32) L = 32;
+  if (L > 1024) L = 1024;
   p.L = (uint32_t)L;
   p.cap = p.nb + (uint32_t)(n / L) + 1;
   uint32_t nchunk = (uint32_t)((n + (1u << 16) - 1) >> 16);  // >= 64K entries per chunk
@@ -99,15 +108,28 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
 // ---------------------------------------------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
-                                                 int W, AddConst K, int16_t* __restrict__ dig) {
+                                                 int W, AddConst K, int16_t* __restrict__ dig,
+                                                 uint32_t* __restrict__ dense_count) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
+  if (!live) i = n - 1;  // keep every lane in the block-wide count below; nothing is stored for it
   Fr s;
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
   uint4 lo = sp[0], hi = sp[1];
   s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
   s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
   if (mont) s = Fr::from_mont(s);
+  {
+    // scalars other than 0 and 1 ("dense" ones): the caller sizes the next call's windows by this count
+    uint32_t hi_bits = s.v[0] >> 1;
+#pragma unroll
+    for (int j = 1; j < 8; j++) hi_bits |= s.v[j];
+    if (dense_count) {  // only the prover asks for it (uniform branch)
+      int cnt = __syncthreads_count(live && hi_bits != 0);
+      if (threadIdx.x == 0 && cnt) atomicAdd(dense_count + (blockIdx.x & 63u), (uint32_t)cnt);
+    }
+  }
+  if (!live) return;
   uint32_t t[9];
   uint64_t cy = 0;
 #pragma unroll

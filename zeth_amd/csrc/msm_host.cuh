@@ -155,13 +155,13 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   const MsmPlan& p = plan;
   ctx->job_W = p.W;
   ctx->job_c = p.c;
-  ZG_TRY(ctx->pinned_reserve((size_t)p.W * sizeof(XYZZ<F>)));
+  ZG_TRY(ctx->pinned_reserve((size_t)p.W * sizeof(XYZZ<F>) + 256));
   if ((uint64_t)p.W * (uint64_t)n >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 32-bit entry positions with headroom
   const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
   const uint32_t nhi = p.nb >= 512 ? (p.nb >> 8) : 0;  // two-level sort when a window has >= 512 buckets
   size_t need = (nhi ? zg_ctx::ws_round(WN * 4) + zg_ctx::ws_round(WN) + 2 * zg_ctx::ws_round((size_t)p.W * (nhi + 1) * 4) : 0) +
                 zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
-                zg_ctx::ws_round((p.W + 1) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
+                zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
   ZG_TRY(ctx->ws_reserve(need));
   int16_t* dig = ctx->ws_take<int16_t>(WN);
@@ -170,7 +170,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   uint32_t* cursor = ctx->ws_take<uint32_t>(WB);
   uint32_t* boff = ctx->ws_take<uint32_t>(WB);
   uint32_t* ufirst = ctx->ws_take<uint32_t>(WB);
-  uint32_t* wunits = ctx->ws_take<uint32_t>(p.W + 1);
+  uint32_t* wunits = ctx->ws_take<uint32_t>(p.W + 1 + 64);  // [W] unit totals, [W] max units per bucket, then 64 dense-scalar counters
   UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
   XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)p.W * p.T);
@@ -197,9 +197,9 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->prof_begin();
   ctx->mark("digits");
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
-                     (size_t)(p.W + 1));
+                     (size_t)(p.W + 1 + 64));
   hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
-                     p.c, p.W, p.K, dig);
+                     p.c, p.W, p.K, dig, ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr);
   ctx->mark("hist");
   hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
   ctx->mark("scan");
@@ -237,6 +237,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   // gather the W window sums (strided by T) with one 2D copy into pinned host memory
   ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), p.W,
                           hipMemcpyDeviceToHost, st));
+  ZG_HIP(hipMemcpyAsync((char*)ctx->pinned + (size_t)p.W * sizeof(XYZZ<F>), wunits + p.W + 1, 256, hipMemcpyDeviceToHost, st));
   return ZG_OK;
 }
 
@@ -250,6 +251,9 @@ int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof_end();
     acc = host_horner(reinterpret_cast<const XYZZ<F>*>(ctx->pinned), ctx->job_W, ctx->job_c);
+    const uint32_t* dc = reinterpret_cast<const uint32_t*>((const char*)ctx->pinned + (size_t)ctx->job_W * sizeof(XYZZ<F>));
+    ctx->job_dense = 0;
+    for (int i = 0; i < 64; i++) ctx->job_dense += dc[i];
   }
   if (out_form == ZG_FORM_XYZZ_INTERNAL) {
     memcpy(out_affine_host, &acc, sizeof(acc));

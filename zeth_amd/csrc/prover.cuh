@@ -105,6 +105,7 @@ struct ProvingKeyDev : PkBase {
   Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
   Fr z_inv;
   zg_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t dense_hint[4] = {0, 0, 0, 0};
   hipEvent_t w_ready = nullptr;
 
   ~ProvingKeyDev() override {
@@ -200,7 +201,10 @@ struct ProvingKeyDev : PkBase {
       host_affine_convert(&beta_g2, 1, 1);
       host_affine_convert(&delta_g2, 1, 1);
     }
-    for (auto& l : lane) ZG_TRY(zg_ctx_create(ctx->device, &l));
+    for (auto& l : lane) {
+      ZG_TRY(zg_ctx_create_prio(ctx->device, +1, &l));
+      l->want_dense = true;
+    }  // equal priority: strict priorities starve the lanes
     ZG_HIP(hipEventCreateWithFlags(&w_ready, hipEventDisableTiming));
     ZG_HIP(hipMalloc((void**)&w, (num_vars + 1) * sizeof(Fr)));
     for (int k = 0; k < 3; k++) ZG_HIP(hipMalloc((void**)&ev[k], m * sizeof(Fr)));
@@ -275,12 +279,18 @@ struct ProvingKeyDev : PkBase {
     XYZZ<Fq> At, Bt1, Ht, Lt;
     XYZZ<Fq2T> Bt2;
     // scalars are Montgomery residues in device memory
-    ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, 0));
-    ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, 0));
-    ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, 0));
-    ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, 0));
+    // Witness scalars are mostly 0/1: the windows of these four evaluations are sized by the number
+    // of other ("dense") scalars the same evaluation saw in the previous proof with this key -- the role libff's
+    // 0/1 filter plays in multi_exp_with_mixed_addition.  Any width gives the same group element.
+    // the longest dependent chain (constraint evaluation, seven transforms, H evaluation) goes first, on the
+    // high-priority main stream; the side lanes have the lowest stream priority
     ZG_TRY(qap_h());
     ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, 0));
+    auto width = [](uint32_t dense) { return dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
+    ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0])));
+    ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1])));
+    ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2])));
+    ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3])));
     stamp("all work queued");
     // Host tail, ordered so that everything that does not need a device result runs while the GPU is busy:
     // the four blinding multiples of delta first, then each evaluation as its lane completes.
@@ -317,6 +327,7 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(o1->msm_finish(lane[2], ZG_FORM_XYZZ_INTERNAL, &Lt));
     stamp("L finished");
     ZG_TRY(o1->msm_finish(ctx, ZG_FORM_XYZZ_INTERNAL, &Ht));
+    for (int i = 0; i < 4; i++) dense_hint[i] = lane[i]->job_n ? lane[i]->job_dense + 1 : 0;
     stamp("H finished");
     XYZZ<Fq> gC = Ht;
     xyzz_add(gC, Lt);
