@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MAC_PER_POINT_BN254_G1 = 21760  # 16 windows x 10 field mults x 136 32-bit MACs
-PEAK_MAC_PER_S = 3.4e13  # v_mad_u64_u32 issue rate measured on MI355X by tools/peak_imul.hip (profiles/)
+PEAK_MAC_PER_S = 3.85e13  # v_mad_u64_u32 issue rate (4.08 cycles per wave64 instruction) measured on MI355X by
+# tools/peak_valu.hip, profiles/r1_peak_valu.jsonl; the microarchitecture guide gives no integer-multiply figure
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
 
 

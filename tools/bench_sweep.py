@@ -14,7 +14,7 @@ from zeth_amd.synth import closed_form_scalar, random_scalars_host  # noqa: E402
 from zeth_model import BLS12_377, BN254  # noqa: E402
 
 MAC = {(0, 1): 21760, (0, 2): 65280, (1, 1): 48000, (1, 2): 144000}  # SURVEY 8d, per point
-PEAK = 3.4e13
+PEAK = 3.85e13
 
 
 def msm_case(ctx, cid, gid, lg, reps=3, check=True):
