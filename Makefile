@@ -8,7 +8,7 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/zeth_gpu.h
 
-all: zeth_amd/libzeth_gpu.so
+all: zeth_amd/libzeth_gpu.so host
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -20,4 +20,20 @@ zeth_amd/libzeth_gpu.so: $(OBJS)
 clean:
 	rm -rf $(OBJDIR) zeth_amd/libzeth_gpu.so
 
-.PHONY: all clean
+.PHONY: all clean host
+
+# C++ host module above the C ABI (include/libzeth_gpu/): the zeth-tool `prove` counterpart and the adapter test driver
+HOSTCXX ?= g++
+HOSTFLAGS ?= -O2 -std=c++17 -Wall -Wextra -Iinclude
+HOSTBINS := build/zeth-gpu-tool build/host_adapter_test
+HOSTHDRS := $(wildcard include/libzeth_gpu/*.hpp) include/zeth_gpu.h
+
+build/zeth-gpu-tool: zeth_amd/host/zeth_gpu_tool.cpp $(HOSTHDRS) zeth_amd/libzeth_gpu.so
+	@mkdir -p build
+	$(HOSTCXX) $(HOSTFLAGS) $< -o $@ -Lzeth_amd -lzeth_gpu -Wl,-rpath,'$$ORIGIN/../zeth_amd' -lpthread
+
+build/host_adapter_test: zeth_amd/host/host_adapter_test.cpp $(HOSTHDRS) zeth_amd/libzeth_gpu.so
+	@mkdir -p build
+	$(HOSTCXX) $(HOSTFLAGS) $< -o $@ -Lzeth_amd -lzeth_gpu -Wl,-rpath,'$$ORIGIN/../zeth_amd' -lpthread
+
+host: $(HOSTBINS)

@@ -1,0 +1,531 @@
+// libzeth/gpu: the C++ host side above the C ABI of zeth_gpu.h -- Zeth's proving entry points with the reference's
+// names, argument meaning and error behaviour, computing on the MI355X through libzeth_gpu.so.
+//
+//   groth16_snark<ppT>::generate_proof(pk, primary, auxiliary)      libzeth/snarks/groth16/groth16_snark.hpp:37-40, .tcc:36-46
+//   r1cs_gg_ppzksnark_prover(pk, primary, auxiliary, force_pow_2)   called at groth16_snark.tcc:44-45
+//   groth16_snark<ppT>::proving_key_{read,write}_bytes, proof_*     groth16_snark.tcc:93-175
+//   is_well_formed<ppT>(pk)                                         groth16_snark.tcc:193-213
+//   multi_exp<ppT, GroupT>(gs, fs) and the iterator overload        libzeth/core/multi_exp.hpp:13-22, .tcc:13-35
+//   basic_radix2_domain<ppT>::{FFT, iFFT, cosetFFT, icosetFFT}      libfqfft, called at libzeth/core/evaluator_from_lagrange.tcc:43
+//   evaluator_from_lagrange<ppT, GroupT>                            libzeth/core/evaluator_from_lagrange.tcc:14-45
+//
+// There is no CPU path behind any of these: without a usable HIP device every call throws std::runtime_error.
+#ifndef LIBZETH_GPU_GROTH16_SNARK_HPP
+#define LIBZETH_GPU_GROTH16_SNARK_HPP
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+
+#include "serialization.hpp"
+#include "types.hpp"
+
+namespace libzeth_gpu
+{
+
+/// One zg_ctx per HIP device, created on first use and shared by the stateless entry points below.  Calls on one
+/// context must not overlap (zeth_gpu.h), so every entry point holds the context's mutex for its duration -- the
+/// one-at-a-time discipline prover_server's shared circuit_wrapper already needs.
+class device_context
+{
+public:
+    static device_context &get(int device = 0)
+    {
+        static std::mutex registry_mutex;
+        static std::map<int, std::unique_ptr<device_context>> registry;
+        std::lock_guard<std::mutex> lock(registry_mutex);
+        std::unique_ptr<device_context> &slot = registry[device];
+        if (!slot) {
+            slot.reset(new device_context(device));
+        }
+        return *slot;
+    }
+    ~device_context() { zg_ctx_destroy(ctx_); }
+    zg_ctx *ctx() const { return ctx_; }
+    std::mutex &mutex() { return mutex_; }
+
+private:
+    explicit device_context(int device) : ctx_(nullptr) { check(zg_ctx_create(device, &ctx_)); }
+    device_context(const device_context &) = delete;
+    zg_ctx *ctx_;
+    std::mutex mutex_;
+};
+
+/// The proving key resident on the device: bases in HBM, constraint matrices as CSR, per-proof scratch.  The
+/// analogue of loading the keypair once before serving proofs (prover_server/prover_server.cpp:449-493,
+/// zeth_tool/prove_cmd.cpp:39-43).
+template<typename ppT> class device_proving_key
+{
+public:
+    device_proving_key(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, int device = 0) : dc_(device_context::get(device)), handle_(nullptr)
+    {
+        using FieldT = Fr<ppT>;
+        const r1cs_constraint_system<FieldT> &cs = pk.constraint_system;
+        const size_t nc = cs.num_constraints();
+        // three CSR matrices over (constraint, variable index)
+        std::vector<uint64_t> row_ptr[3];
+        std::vector<uint32_t> col[3];
+        std::vector<FieldT> val[3];
+        for (int k = 0; k < 3; k++) {
+            row_ptr[k].reserve(nc + 1);
+            row_ptr[k].push_back(0);
+        }
+        for (const r1cs_constraint<FieldT> &c : cs.constraints) {
+            const linear_combination<FieldT> *lcs[3] = {&c.a, &c.b, &c.c};
+            for (int k = 0; k < 3; k++) {
+                for (const linear_term<FieldT> &t : lcs[k]->terms) {
+                    if (t.index > cs.num_variables()) {
+                        throw std::invalid_argument("constraint system: variable index out of range");
+                    }
+                    col[k].push_back((uint32_t)t.index);
+                    val[k].push_back(t.coeff);
+                }
+                row_ptr[k].push_back(col[k].size());
+            }
+        }
+        if (pk.B_query.indices.size() != pk.B_query.values.size()) {
+            throw std::invalid_argument("proving key: B_query indices / values size mismatch");
+        }
+        const size_t nb = pk.B_query.indices.size();
+        std::vector<uint32_t> b_idx(nb);
+        G2_vector<ppT> b_g2(nb);
+        G1_vector<ppT> b_g1(nb);
+        for (size_t i = 0; i < nb; i++) {
+            if (pk.B_query.indices[i] > cs.num_variables()) {
+                throw std::invalid_argument("proving key: B_query index out of range");
+            }
+            b_idx[i] = (uint32_t)pk.B_query.indices[i];
+            b_g2[i] = pk.B_query.values[i].g;
+            b_g1[i] = pk.B_query.values[i].h;
+        }
+        zg_pk_view v;
+        memset(&v, 0, sizeof(v));
+        v.num_inputs = cs.num_inputs();
+        v.num_variables = cs.num_variables();
+        v.num_constraints = nc;
+        zg_r1cs_matrix *mats[3] = {&v.a, &v.b, &v.c};
+        for (int k = 0; k < 3; k++) {
+            mats[k]->row_ptr = row_ptr[k].data();
+            mats[k]->col = col[k].data();
+            mats[k]->val = val[k].data();
+        }
+        v.alpha_g1 = &pk.alpha_g1;
+        v.beta_g1 = &pk.beta_g1;
+        v.beta_g2 = &pk.beta_g2;
+        v.delta_g1 = &pk.delta_g1;
+        v.delta_g2 = &pk.delta_g2;
+        v.A_query = pk.A_query.data();
+        v.A_len = pk.A_query.size();
+        v.B_indices = b_idx.data();
+        v.B_g2 = b_g2.data();
+        v.B_g1 = b_g1.data();
+        v.B_len = nb;
+        v.H_query = pk.H_query.data();
+        v.H_len = pk.H_query.size();
+        v.L_query = pk.L_query.data();
+        v.L_len = pk.L_query.size();
+        v.form = ZG_FORM_PLAIN;
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        check(zg_pk_create(dc_.ctx(), ppT::curve_id, &v, &handle_));
+    }
+    ~device_proving_key()
+    {
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        zg_pk_free(handle_);
+    }
+    device_proving_key(const device_proving_key &) = delete;
+    device_proving_key &operator=(const device_proving_key &) = delete;
+
+    size_t domain_size() const
+    {
+        size_t m = 0;
+        check(zg_pk_domain_size(handle_, &m));
+        return m;
+    }
+
+    /// The prover with its randomness passed in (r, s plain): reproducible proofs for tests.
+    r1cs_gg_ppzksnark_proof<ppT> prove(
+        const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary, const Fr<ppT> &r, const Fr<ppT> &s) const
+    {
+        r1cs_gg_ppzksnark_proof<ppT> proof;
+        static_assert(sizeof(proof) == 2 * sizeof(G1<ppT>) + sizeof(G2<ppT>), "proof must be g_A || g_B || g_C without padding");
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        check(zg_prove(
+            handle_, primary.data(), primary.size(), auxiliary.data(), auxiliary.size(), ZG_FORM_PLAIN, r.data, s.data, ZG_FORM_PLAIN, &proof));
+        return proof;
+    }
+
+    /// libsnark::r1cs_to_qap_witness_map(...).coefficients_for_H (domain size + 1 values)
+    std::vector<Fr<ppT>> witness_map(const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary) const
+    {
+        std::vector<Fr<ppT>> h(domain_size() + 1);
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        check(zg_witness_map(
+            handle_, primary.data(), primary.size(), auxiliary.data(), auxiliary.size(), ZG_FORM_PLAIN, ZG_FORM_PLAIN, h.data()));
+        return h;
+    }
+
+private:
+    device_context &dc_;
+    zg_pk *handle_;
+};
+
+/// Fr::random_element(): uniform in [0, r) from the OS entropy source (libsnark draws the prover's r and s this
+/// way, inside the prover -- SURVEY 8b).
+template<typename ppT> Fr<ppT> random_field_element()
+{
+    std::random_device rd;
+    const uint64_t top_mask = (ppT::r_bits % 64) ? ((uint64_t(1) << (ppT::r_bits % 64)) - 1) : ~uint64_t(0);
+    for (;;) {
+        Fr<ppT> x;
+        for (size_t i = 0; i < 4; i++) {
+            x.data[i] = ((uint64_t)rd() << 32) | (uint64_t)rd();
+        }
+        x.data[3] &= top_mask;
+        if (x.less_than(ppT::r)) {
+            return x;
+        }
+    }
+}
+
+namespace internal
+{
+// Device keys built by the stateless entry points, by host key address.  A fingerprint of the key's sizes and of a
+// few of its elements guards against a different key reusing the address.
+template<typename ppT> struct device_key_cache {
+    struct entry {
+        uint64_t fingerprint;
+        std::shared_ptr<device_proving_key<ppT>> key;
+    };
+    static uint64_t fingerprint(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
+    {
+        uint64_t h = 0xcbf29ce484222325ull;
+        auto mix = [&h](const void *p, size_t n) {
+            const uint8_t *b = (const uint8_t *)p;
+            for (size_t i = 0; i < n; i++) {
+                h = (h ^ b[i]) * 0x100000001b3ull;
+            }
+        };
+        const size_t sizes[6] = {pk.A_query.size(),
+                                 pk.B_query.values.size(),
+                                 pk.H_query.size(),
+                                 pk.L_query.size(),
+                                 pk.constraint_system.num_constraints(),
+                                 pk.constraint_system.num_variables()};
+        mix(sizes, sizeof(sizes));
+        mix(&pk.alpha_g1, sizeof(pk.alpha_g1));
+        mix(&pk.delta_g1, sizeof(pk.delta_g1));
+        if (!pk.A_query.empty()) {
+            mix(&pk.A_query.front(), sizeof(G1<ppT>));
+            mix(&pk.A_query.back(), sizeof(G1<ppT>));
+        }
+        if (!pk.H_query.empty()) {
+            mix(&pk.H_query.back(), sizeof(G1<ppT>));
+        }
+        if (!pk.L_query.empty()) {
+            mix(&pk.L_query.back(), sizeof(G1<ppT>));
+        }
+        return h;
+    }
+    static std::shared_ptr<device_proving_key<ppT>> lookup(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
+    {
+        static std::mutex m;
+        static std::map<const void *, entry> cache;
+        std::lock_guard<std::mutex> lock(m);
+        const uint64_t fp = fingerprint(pk);
+        auto it = cache.find(&pk);
+        if (it != cache.end() && it->second.fingerprint == fp) {
+            return it->second.key;
+        }
+        entry e{fp, std::make_shared<device_proving_key<ppT>>(pk)};
+        cache[&pk] = e;
+        return e.key;
+    }
+};
+} // namespace internal
+
+/// libsnark::r1cs_gg_ppzksnark_prover as Zeth calls it.  The key is uploaded on first use and stays resident for the
+/// process lifetime.  Zeth always passes force_pow_2_domain = true (groth16_snark.tcc:43-45); the device transforms
+/// are radix-2 only, so false is rejected.
+template<typename ppT>
+r1cs_gg_ppzksnark_proof<ppT> r1cs_gg_ppzksnark_prover(
+    const r1cs_gg_ppzksnark_proving_key<ppT> &pk,
+    const r1cs_primary_input<Fr<ppT>> &primary_input,
+    const r1cs_auxiliary_input<Fr<ppT>> &auxiliary_input,
+    bool force_pow_2_domain)
+{
+    if (!force_pow_2_domain) {
+        throw std::invalid_argument("r1cs_gg_ppzksnark_prover: only power-of-two domains are supported");
+    }
+    const std::shared_ptr<device_proving_key<ppT>> dpk = internal::device_key_cache<ppT>::lookup(pk);
+    return dpk->prove(primary_input, auxiliary_input, random_field_element<ppT>(), random_field_element<ppT>());
+}
+
+template<typename ppT> bool container_is_well_formed(const G1_vector<ppT> &points)
+{
+    size_t bad = 0;
+    check(zg_host_points_check(ppT::curve_id, ZG_GROUP_G1, points.data(), points.size(), ZG_FORM_PLAIN, &bad));
+    return bad == points.size();
+}
+
+template<typename ppT> bool group_element_is_well_formed(const G1<ppT> &p)
+{
+    size_t bad = 0;
+    check(zg_host_points_check(ppT::curve_id, ZG_GROUP_G1, &p, 1, ZG_FORM_PLAIN, &bad));
+    return bad == 1;
+}
+
+template<typename ppT> bool group_element_is_well_formed(const G2<ppT> &p)
+{
+    size_t bad = 0;
+    check(zg_host_points_check(ppT::curve_id, ZG_GROUP_G2, &p, 1, ZG_FORM_PLAIN, &bad));
+    return bad == 1;
+}
+
+/// groth16_snark.tcc:193-213: alpha, beta, delta, A_query, L_query and every B_query entry are on their curves
+/// (like the reference, H_query is not checked)
+template<typename ppT> bool is_well_formed(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
+{
+    if (!group_element_is_well_formed<ppT>(pk.alpha_g1) || !group_element_is_well_formed<ppT>(pk.beta_g1) ||
+        !group_element_is_well_formed<ppT>(pk.beta_g2) || !group_element_is_well_formed<ppT>(pk.delta_g1) ||
+        !group_element_is_well_formed<ppT>(pk.delta_g2) || !container_is_well_formed<ppT>(pk.A_query) ||
+        !container_is_well_formed<ppT>(pk.L_query)) {
+        return false;
+    }
+    for (const auto &b : pk.B_query.values) {
+        if (!group_element_is_well_formed<ppT>(b.g) || !group_element_is_well_formed<ppT>(b.h)) {
+            return false;
+        }
+    }
+    return true;
+}
+
+/// The proving half of libzeth::groth16_snark<ppT> (groth16_snark.hpp:15-79).  Setup and verification stay with
+/// libsnark on the CPU: they are outside the accelerated path.
+template<typename ppT> class groth16_snark
+{
+public:
+    using proving_key = r1cs_gg_ppzksnark_proving_key<ppT>;
+    using proof = r1cs_gg_ppzksnark_proof<ppT>;
+
+    static constexpr const char *name = "GROTH16";
+
+    static proof generate_proof(
+        const proving_key &proving_key, const r1cs_primary_input<Fr<ppT>> &primary_input, const r1cs_auxiliary_input<Fr<ppT>> auxiliary_input)
+    {
+        // "For now, force a pow2 domain, in case the key came from the MPC" (groth16_snark.tcc:42-45)
+        return r1cs_gg_ppzksnark_prover<ppT>(proving_key, primary_input, auxiliary_input, true);
+    }
+
+    static void proving_key_write_bytes(const proving_key &pk, std::ostream &out_s)
+    {
+        if (!is_well_formed<ppT>(pk)) {
+            throw std::invalid_argument("proving key (write) not well-formed");
+        }
+        group_element_write_bytes(pk.alpha_g1, out_s);
+        group_element_write_bytes(pk.beta_g1, out_s);
+        group_element_write_bytes(pk.beta_g2, out_s);
+        group_element_write_bytes(pk.delta_g1, out_s);
+        group_element_write_bytes(pk.delta_g2, out_s);
+        group_elements_write_bytes(pk.A_query, out_s);
+        knowledge_commitment_vector_write_bytes(pk.B_query, out_s);
+        group_elements_write_bytes(pk.H_query, out_s);
+        group_elements_write_bytes(pk.L_query, out_s);
+        r1cs_write_bytes(pk.constraint_system, out_s);
+    }
+
+    static void proving_key_read_bytes(proving_key &pk, std::istream &in_s)
+    {
+        group_element_read_bytes(pk.alpha_g1, in_s);
+        group_element_read_bytes(pk.beta_g1, in_s);
+        group_element_read_bytes(pk.beta_g2, in_s);
+        group_element_read_bytes(pk.delta_g1, in_s);
+        group_element_read_bytes(pk.delta_g2, in_s);
+        group_elements_read_bytes(pk.A_query, in_s);
+        knowledge_commitment_vector_read_bytes(pk.B_query, in_s);
+        group_elements_read_bytes(pk.H_query, in_s);
+        group_elements_read_bytes(pk.L_query, in_s);
+        r1cs_read_bytes(pk.constraint_system, in_s);
+        if (!is_well_formed<ppT>(pk)) {
+            throw std::invalid_argument("proving key (read) not well-formed");
+        }
+    }
+
+    static void proof_write_bytes(const proof &proof, std::ostream &out_s)
+    {
+        group_element_write_bytes(proof.g_A, out_s);
+        group_element_write_bytes(proof.g_B, out_s);
+        group_element_write_bytes(proof.g_C, out_s);
+    }
+
+    static void proof_read_bytes(proof &proof, std::istream &in_s)
+    {
+        group_element_read_bytes(proof.g_A, in_s);
+        group_element_read_bytes(proof.g_B, in_s);
+        group_element_read_bytes(proof.g_C, in_s);
+    }
+
+    static void proof_write_json(const proof &proof, std::ostream &out_s)
+    {
+        out_s << "{\n  \"a\": " << group_element_to_json(proof.g_A) << ",\n  \"b\": " << group_element_to_json(proof.g_B)
+              << ",\n  \"c\": " << group_element_to_json(proof.g_C) << "\n}";
+    }
+};
+
+// ---- libzeth::multi_exp (libzeth/core/multi_exp.hpp:13-22) ----
+
+/// Base points kept in HBM across calls (the `gs` of multi_exp uploaded once).
+template<typename ppT, typename GroupT> class resident_bases
+{
+public:
+    explicit resident_bases(const std::vector<GroupT> &gs, int device = 0) : dc_(device_context::get(device)), handle_(nullptr), size_(gs.size())
+    {
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        check(zg_bases_create(dc_.ctx(), ppT::curve_id, GroupT::group_id, gs.data(), gs.size(), ZG_FORM_PLAIN, ZG_MEM_HOST, &handle_));
+    }
+    ~resident_bases()
+    {
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        zg_bases_free(handle_);
+    }
+    resident_bases(const resident_bases &) = delete;
+    resident_bases &operator=(const resident_bases &) = delete;
+    size_t size() const { return size_; }
+
+    /// sum_i fs[i] * gs[first + i]
+    GroupT multi_exp(const Fr<ppT> *fs, size_t n, size_t first = 0) const
+    {
+        GroupT out;
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        check(zg_msm(handle_, first, fs, n, ZG_FORM_PLAIN, ZG_MEM_HOST, ZG_FORM_PLAIN, &out));
+        return out;
+    }
+    GroupT multi_exp(const Fr_vector<ppT> &fs) const { return multi_exp(fs.data(), fs.size(), 0); }
+
+private:
+    device_context &dc_;
+    zg_bases *handle_;
+    size_t size_;
+};
+
+template<typename ppT, typename GroupT>
+GroupT multi_exp(
+    typename std::vector<GroupT>::const_iterator gs_start,
+    typename std::vector<GroupT>::const_iterator gs_end,
+    typename std::vector<Fr<ppT>>::const_iterator fs_start,
+    typename std::vector<Fr<ppT>>::const_iterator fs_end)
+{
+    const size_t ng = (size_t)(gs_end - gs_start), nf = (size_t)(fs_end - fs_start);
+    if (ng != nf) {
+        // libff::multi_exp_filter_one_zero asserts equal lengths
+        throw std::invalid_argument("multi_exp: base and scalar ranges differ in length");
+    }
+    if (nf == 0) {
+        return GroupT::zero();
+    }
+    device_context &dc = device_context::get();
+    zg_bases *b = nullptr;
+    GroupT out;
+    std::lock_guard<std::mutex> lock(dc.mutex());
+    check(zg_bases_create(dc.ctx(), ppT::curve_id, GroupT::group_id, &*gs_start, ng, ZG_FORM_PLAIN, ZG_MEM_HOST, &b));
+    const int s = zg_msm(b, 0, &*fs_start, nf, ZG_FORM_PLAIN, ZG_MEM_HOST, ZG_FORM_PLAIN, &out);
+    zg_bases_free(b);
+    check(s);
+    return out;
+}
+
+template<typename ppT, typename GroupT> GroupT multi_exp(const std::vector<GroupT> &gs, const Fr_vector<ppT> &fs)
+{
+    // the reference asserts gs.size() >= fs.size() and gs.size() > 0 (multi_exp.tcc:28-29) and uses the first
+    // fs.size() bases
+    if (gs.size() < fs.size() || gs.empty()) {
+        throw std::invalid_argument("multi_exp: fewer bases than scalars");
+    }
+    return multi_exp<ppT, GroupT>(gs.begin(), gs.begin() + fs.size(), fs.begin(), fs.end());
+}
+
+// ---- libfqfft::basic_radix2_domain<Fr> as Zeth uses it ----
+template<typename ppT> class basic_radix2_domain
+{
+public:
+    const size_t m;
+
+    explicit basic_radix2_domain(size_t m_) : m(m_), log_m_(0)
+    {
+        // libfqfft throws DomainSizeException for sizes that are not a power of two or exceed the 2-adicity
+        if (m_ <= 1 || (m_ & (m_ - 1)) != 0) {
+            throw std::invalid_argument("basic_radix2(): expected m == (1 << log2(m)), m > 1");
+        }
+        while ((size_t(1) << log_m_) < m_) {
+            log_m_++;
+        }
+        if (log_m_ > ppT::two_adicity) {
+            throw std::invalid_argument("basic_radix2(): expected log2(m) <= Fr::s");
+        }
+    }
+    void FFT(std::vector<Fr<ppT>> &a) const { run(a, 0, 0); }
+    void iFFT(std::vector<Fr<ppT>> &a) const { run(a, 1, 0); }
+    /// g must be Fr::multiplicative_generator, the only shift the prover and Zeth use
+    void cosetFFT(std::vector<Fr<ppT>> &a, const Fr<ppT> &g) const
+    {
+        require_generator(g);
+        run(a, 0, 1);
+    }
+    void icosetFFT(std::vector<Fr<ppT>> &a, const Fr<ppT> &g) const
+    {
+        require_generator(g);
+        run(a, 1, 1);
+    }
+
+private:
+    unsigned log_m_;
+    static void require_generator(const Fr<ppT> &g)
+    {
+        if (g != Fr<ppT>(ppT::multiplicative_generator)) {
+            throw std::invalid_argument("coset transforms support the shift Fr::multiplicative_generator only");
+        }
+    }
+    void run(std::vector<Fr<ppT>> &a, int inverse, int coset) const
+    {
+        if (a.size() != m) {
+            throw std::invalid_argument("basic_radix2: expected a.size() == this->m"); // libfqfft DomainSizeException
+        }
+        device_context &dc = device_context::get();
+        std::lock_guard<std::mutex> lock(dc.mutex());
+        check(zg_ntt(dc.ctx(), ppT::curve_id, a.data(), log_m_, inverse, coset, ZG_FORM_PLAIN, ZG_MEM_HOST));
+    }
+};
+
+/// libzeth::evaluator_from_lagrange (evaluator_from_lagrange.tcc:14-45): scatter the Lagrange factors into a
+/// domain-sized vector, iFFT to coefficients, multi_exp against the powers.
+template<typename ppT, typename GroupT> class evaluator_from_lagrange
+{
+public:
+    evaluator_from_lagrange(const std::vector<GroupT> &powers, const basic_radix2_domain<ppT> &domain) : powers_(powers), domain_(domain)
+    {
+        if (powers.size() < domain.m) {
+            throw std::invalid_argument("evaluator_from_lagrange: fewer powers than the domain size");
+        }
+    }
+    GroupT evaluate_from_lagrange_factors(const std::map<size_t, Fr<ppT>> &lagrange_factors) const
+    {
+        std::vector<Fr<ppT>> coefficients(domain_.m, Fr<ppT>::zero());
+        for (const auto &it : lagrange_factors) {
+            if (it.first >= domain_.m) {
+                throw std::invalid_argument("evaluator_from_lagrange: factor index outside the domain");
+            }
+            coefficients[it.first] = it.second;
+        }
+        domain_.iFFT(coefficients);
+        return multi_exp<ppT, GroupT>(powers_, coefficients);
+    }
+
+private:
+    const std::vector<GroupT> &powers_;
+    const basic_radix2_domain<ppT> &domain_;
+};
+
+} // namespace libzeth_gpu
+
+#endif // LIBZETH_GPU_GROTH16_SNARK_HPP

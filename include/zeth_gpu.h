@@ -158,6 +158,12 @@ int zg_witness_map(zg_pk* pk, const void* primary, size_t n_primary, const void*
  * exported so tests can pin it without a GPU.  op: 0 = a + b, 1 = k * a (k: Fr plain 32 B in `b`) */
 int zg_host_group_op(int curve, int group, int op, const void* a_affine, const void* b, int form, void* out_affine);
 
+/* libff's G::is_well_formed() over n affine points (the identity, or Y^2 = X^3 + b), on the host: what
+ * groth16_snark<ppT>::proving_key_read_bytes runs on a key it has just read
+ * (libzeth/snarks/groth16/groth16_snark.tcc:145-147, 193-213).  *first_bad = n when every point passes, else the
+ * index of the first point off the curve. */
+int zg_host_points_check(int curve, int group, const void* points, size_t n, int form, size_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -766,6 +766,79 @@ def g2_to_json(curve: Curve, P) -> str:
     return '[["0x%s","0x%s"],["0x%s","0x%s"]]' % (h(x1), h(x0), h(y1), h(y0))
 
 
+# Stream formats (libzeth/serialization/stream_utils.tcc, r1cs_serialization.tcc:199-275,
+# r1cs_variable_assignment_serialization.tcc:15-77, snarks/groth16/groth16_snark.tcc:93-175): size_t and
+# var_index_t are native 8-byte little-endian, the per-linear-combination term count is a uint32.
+def fr_to_bytes(x: int) -> bytes:
+    return x.to_bytes(32, "big")
+
+
+def _u64(x: int) -> bytes:
+    return x.to_bytes(8, "little")
+
+
+def g1_vector_to_bytes(curve: Curve, pts) -> bytes:
+    return _u64(len(pts)) + b"".join(g1_to_bytes(curve, P) for P in pts)
+
+
+def g2_vector_to_bytes(curve: Curve, pts) -> bytes:
+    return _u64(len(pts)) + b"".join(g2_to_bytes(curve, P) for P in pts)
+
+
+def linear_combination_to_bytes(curve: Curve, lc) -> bytes:
+    """lc: dict or list of (index, coeff) pairs, written in stored order."""
+    terms = list(lc.items()) if isinstance(lc, dict) else list(lc)
+    out = len(terms).to_bytes(4, "little")
+    for idx, coeff in terms:
+        out += _u64(idx) + fr_to_bytes(coeff % curve.r)
+    return out
+
+
+def r1cs_to_bytes(curve: Curve, cs: "R1CS") -> bytes:
+    out = _u64(cs.num_inputs) + _u64(cs.num_aux) + _u64(cs.num_constraints)
+    for a, b, c in cs.constraints:
+        out += linear_combination_to_bytes(curve, a) + linear_combination_to_bytes(curve, b) + linear_combination_to_bytes(curve, c)
+    return out
+
+
+def assignment_to_bytes(curve: Curve, values) -> bytes:
+    return _u64(len(values)) + b"".join(fr_to_bytes(v % curve.r) for v in values)
+
+
+def assignment_from_bytes(b: bytes):
+    n = int.from_bytes(b[:8], "little")
+    assert len(b) == 8 + 32 * n
+    return [int.from_bytes(b[8 + 32 * i : 40 + 32 * i], "big") for i in range(n)]
+
+
+def proving_key_to_bytes(curve: Curve, pk: "ProvingKey") -> bytes:
+    out = g1_to_bytes(curve, pk.alpha_g1) + g1_to_bytes(curve, pk.beta_g1) + g2_to_bytes(curve, pk.beta_g2)
+    out += g1_to_bytes(curve, pk.delta_g1) + g2_to_bytes(curve, pk.delta_g2)
+    out += g1_vector_to_bytes(curve, pk.A_query)
+    parts = [_u64(pk.B_domain_size), _u64(len(pk.B_query))]
+    for idx, g2p, g1p in pk.B_query:  # knowledge_commitment: g (G2) then h (G1)
+        parts.append(_u64(idx) + g2_to_bytes(curve, g2p) + g1_to_bytes(curve, g1p))
+    out += b"".join(parts)
+    out += g1_vector_to_bytes(curve, pk.H_query) + g1_vector_to_bytes(curve, pk.L_query)
+    return out + r1cs_to_bytes(curve, pk.cs)
+
+
+def proof_to_bytes(curve: Curve, proof) -> bytes:
+    g_A, g_B, g_C = proof
+    return g1_to_bytes(curve, g_A) + g2_to_bytes(curve, g_B) + g1_to_bytes(curve, g_C)
+
+
+def proof_from_bytes(curve: Curve, b: bytes):
+    n = curve.fq_bytes
+    assert len(b) == 8 * n
+    return g1_from_bytes(curve, b[: 2 * n]), g2_from_bytes(curve, b[2 * n : 6 * n]), g1_from_bytes(curve, b[6 * n :])
+
+
+def proof_to_json(curve: Curve, proof) -> str:
+    g_A, g_B, g_C = proof
+    return '{\n  "a": %s,\n  "b": %s,\n  "c": %s\n}' % (g1_to_json(curve, g_A), g2_to_json(curve, g_B), g1_to_json(curve, g_C))
+
+
 # powersoftau encodings (powersoftau_utils.tcc:485-505, 590-622): 0x04 marker, Fq2 packed as c1*q + c0
 def pot_read_g1(curve: Curve, b: bytes, off: int):
     n = curve.fq_bytes

@@ -1,0 +1,148 @@
+"""GPU parity for the C++ host module (include/libzeth_gpu/gpu_groth16_snark.hpp) and the zeth-tool `prove`
+counterpart (zeth_amd/host/zeth_gpu_tool.cpp): every result crosses Zeth's on-disk formats, is produced by the C++
+adapter calling the C ABI, and is compared with the oracle bit for bit.
+
+Mirrors the reference's own tests: proof round trip and verification on the simple circuit
+(libzeth/tests/snarks/common_snark_tests.tcc:37-62, libzeth/tests/circuits/simple_test.cpp:134-154), iFFT + multi_exp
+against the Lagrange evaluations on real powersoftau data (libzeth/tests/core/evaluator_from_lagrange_test.cpp:21-66
+with testdata/powersoftau_challenge.4.bin)."""
+import os
+import random
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import zeth_model as M  # noqa: E402
+from zeth_model import BLS12_377, BN254  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "build", "host_adapter_test")
+TOOL = os.path.join(ROOT, "build", "zeth-gpu-tool")
+CURVES = {"alt-bn128": BN254, "bls12-377": BLS12_377}
+
+
+def run(*args, expect=0):
+    p = subprocess.run([str(a) for a in args], capture_output=True, text=True, timeout=110)
+    assert p.returncode == expect, "exit %d (wanted %d)\nstdout: %s\nstderr: %s" % (p.returncode, expect, p.stdout, p.stderr)
+    return p
+
+
+def simple_instance(C, xs):
+    cs = M.simple_circuit(C, len(xs))
+    pk, vk = M.generator_from_secrets(C, cs, 0x1234567, 0x2345678, 0x3456789, 0x456789A)
+    primary, aux = M.simple_circuit_assignment(C, xs)
+    return cs, pk, vk, primary, aux
+
+
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_tool_prove_matches_oracle(curve, tmp_path):
+    C = CURVES[curve]
+    cs, pk, vk, primary, aux = simple_instance(C, [10, 12, 14, 16])
+    (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    rng = random.Random(7)
+    r, s = rng.randrange(C.r), rng.randrange(C.r)
+    out = run(TOOL, "prove", "-c", curve, "--profile", "--randomness", "%x" % r, "0x%x" % s, tmp_path / "pk", tmp_path / "asg",
+              tmp_path / "proof")
+    assert "Writing proof to file" in out.stdout and "(profile) generate_proof" in out.stdout
+    want = M.prove(C, pk, primary, aux, r, s)
+    assert (tmp_path / "proof").read_bytes() == M.proof_to_bytes(C, want)
+    # default randomness (drawn inside the prover, as libsnark does): a different proof each run, each one valid
+    seen = set()
+    for k in range(2):
+        run(TOOL, "prove", "--curve", curve, "-p", 1, tmp_path / "pk", tmp_path / "asg", tmp_path / ("p%d" % k))
+        raw = (tmp_path / ("p%d" % k)).read_bytes()
+        assert M.verify(C, vk, primary, M.proof_from_bytes(C, raw))
+        seen.add(raw)
+    assert len(seen) == 2
+
+
+def test_tool_prove_unsatisfied_assignment_is_not_an_error(tmp_path):
+    """libzeth/tests/prover/prover_test.cpp:703-714: a bad witness yields a proof that fails to verify."""
+    C = BN254
+    cs, pk, vk, primary, aux = simple_instance(C, [78])
+    aux = list(aux)
+    aux[1] = (aux[1] + 1) % C.r
+    (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    run(TOOL, "prove", tmp_path / "pk", tmp_path / "asg", tmp_path / "proof")
+    assert not M.verify(C, vk, primary, M.proof_from_bytes(C, (tmp_path / "proof").read_bytes()))
+    # wrong number of values for this key: std::invalid_argument -> exit 1
+    (tmp_path / "short").write_bytes(M.assignment_to_bytes(C, primary + aux[:-1]))
+    assert "invalid argument" in run(TOOL, "prove", tmp_path / "pk", tmp_path / "short", tmp_path / "proof2", expect=1).stderr
+
+
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_adapter_generate_proof(curve, tmp_path):
+    """groth16_snark<ppT>::generate_proof(pk, primary, auxiliary) through the stateless entry point (resident key
+    reused on the second call) and device_proving_key::prove with fixed (r, s)."""
+    C = CURVES[curve]
+    cs, pk, vk, primary, aux = simple_instance(C, [3, 5])
+    (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    r, s = 0x1F2E3D4C5B6A7988 % C.r, 0x123456789ABCDEF0123456789 % C.r
+    run(DRIVER, "prove", curve, tmp_path / "pk", tmp_path / "asg", 1, "%x" % r, "%x" % s, tmp_path / "fixed", tmp_path / "r1", tmp_path / "r2")
+    assert (tmp_path / "fixed").read_bytes() == M.proof_to_bytes(C, M.prove(C, pk, primary, aux, r, s))
+    p1, p2 = (tmp_path / "r1").read_bytes(), (tmp_path / "r2").read_bytes()
+    assert p1 != p2
+    assert M.verify(C, vk, primary, M.proof_from_bytes(C, p1)) and M.verify(C, vk, primary, M.proof_from_bytes(C, p2))
+
+
+@pytest.mark.parametrize("curve,group", [("alt-bn128", "g1"), ("alt-bn128", "g2"), ("bls12-377", "g1"), ("bls12-377", "g2")])
+def test_adapter_multi_exp(curve, group, tmp_path):
+    """libzeth::multi_exp<ppT, GroupT>(gs, fs) (multi_exp.tcc:25-35): more bases than scalars is allowed and uses the
+    first fs.size(); fewer is an error."""
+    C = CURVES[curve]
+    G = C.G1 if group == "g1" else C.G2
+    to_bytes = M.g1_vector_to_bytes if group == "g1" else M.g2_vector_to_bytes
+    one_to_bytes = M.g1_to_bytes if group == "g1" else M.g2_to_bytes
+    rng = random.Random(11)
+    n = 300
+    pts = [G.mul(rng.randrange(1, C.r), G.gen) for _ in range(8)]
+    gs = [pts[i % 8] if i % 17 else None for i in range(n + 5)]
+    fs = [rng.choice([0, 1, C.r - 1, rng.randrange(C.r)]) for _ in range(n)]
+    (tmp_path / "gs").write_bytes(to_bytes(C, gs))
+    (tmp_path / "fs").write_bytes(M.assignment_to_bytes(C, fs))
+    run(DRIVER, "multi_exp", curve, group, tmp_path / "gs", tmp_path / "fs", tmp_path / "out")
+    assert (tmp_path / "out").read_bytes() == one_to_bytes(C, G.multi_exp(gs[:n], fs))
+    (tmp_path / "few").write_bytes(to_bytes(C, gs[:10]))
+    run(DRIVER, "multi_exp", curve, group, tmp_path / "few", tmp_path / "fs", tmp_path / "out2", expect=10)
+
+
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_adapter_domain(curve, tmp_path):
+    C = CURVES[curve]
+    rng = random.Random(5)
+    m = 64
+    a = [rng.randrange(C.r) for _ in range(m)]
+    (tmp_path / "in").write_bytes(M.assignment_to_bytes(C, a))
+    dom = M.Domain(C, m)
+    for op, fn in (("fft", dom.FFT), ("ifft", dom.iFFT), ("cosetfft", lambda v: dom.cosetFFT(v, C.fr_gen)),
+                   ("icosetfft", lambda v: dom.icosetFFT(v, C.fr_gen))):
+        run(DRIVER, "domain", curve, op, tmp_path / "in", tmp_path / op)
+        want = list(a)
+        fn(want)
+        assert M.assignment_from_bytes((tmp_path / op).read_bytes()) == want, op
+    # not a power of two: the domain constructor throws (libfqfft DomainSizeException)
+    (tmp_path / "odd").write_bytes(M.assignment_to_bytes(C, a[:48]))
+    run(DRIVER, "domain", curve, "fft", tmp_path / "odd", tmp_path / "x", expect=10)
+
+
+def test_evaluator_from_lagrange_on_powersoftau_data(golden_dir, tmp_path):
+    """evaluator_from_lagrange_test.cpp:21-66 on the reference's powersoftau_challenge.4.bin (n = 16): for every j,
+    iFFT(e_j) dotted with the tau powers equals [L_j(tau)], which is checked here against the definition
+    L_j = (1/n) sum_i omega^(-ij) [tau^i] computed with the oracle's group law."""
+    C = BN254
+    n = 16
+    pot, _ = M.pot_load(C, open(os.path.join(golden_dir, "powersoftau_challenge.4.bin"), "rb").read(), n)
+    omega_inv = pow(C.omega(n), -1, C.r)
+    n_inv = pow(n, -1, C.r)
+    for group, G, powers, to_bytes in (("g1", C.G1, pot["tau_g1"][:n], M.g1_vector_to_bytes),
+                                       ("g2", C.G2, pot["tau_g2"][:n], M.g2_vector_to_bytes),
+                                       ("g1", C.G1, pot["alpha_tau_g1"][:n], M.g1_vector_to_bytes)):
+        (tmp_path / "powers").write_bytes(to_bytes(C, powers))
+        run(DRIVER, "lagrange", "alt-bn128", group, tmp_path / "powers", tmp_path / "out")
+        want = [G.multi_exp(powers, [pow(omega_inv, i * j, C.r) * n_inv % C.r for i in range(n)]) for j in range(n)]
+        assert (tmp_path / "out").read_bytes() == to_bytes(C, want)

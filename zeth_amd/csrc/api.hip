@@ -41,6 +41,7 @@ int zg_sizes(int curve, size_t* fr, size_t* fq, size_t* g1, size_t* g2) {
 
 int zg_ctx_create(int device, zg_ctx** out) { return zg_ctx_create_prio(device, +1, out); }
 
+
 }  // extern "C"
 
 // prio > 0: highest stream priority (a context's main stream: the latency-critical chain), prio < 0: lowest (side lanes)
@@ -396,6 +397,13 @@ int zg_host_group_op(int curve, int group, int op, const void* a, const void* b,
   const GroupOps* ops = zg_group_ops(curve, group);
   if (!ops || !a || !b || !out) return ZG_ERR_INVALID_ARGUMENT;
   return ops->host_op(op, a, b, form, out);
+}
+
+
+int zg_host_points_check(int curve, int group, const void* points, size_t n, int form, size_t* first_bad) {
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ops || (n && !points) || !first_bad || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;
+  return ops->points_check(points, n, form, first_bad);
 }
 
 }  // extern "C"

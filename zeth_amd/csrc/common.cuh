@@ -128,6 +128,8 @@ struct GroupOps {
   int (*host_op)(int op, const void* a, const void* b, int form, void* out);
   // host-side conversion of `n` affine points between forms, in place (mont <-> plain)
   void (*host_convert)(void* pts, size_t n, int to_mont);
+  // host-side curve-equation check of n affine points; *first_bad = n when all pass
+  int (*points_check)(const void* pts, size_t n, int form, size_t* first_bad);
 };
 
 const GroupOps* zg_group_ops(int curve, int group);

@@ -334,6 +334,26 @@ void host_convert_thunk(void* pts, size_t n, int to_mont) {
   host_affine_convert(reinterpret_cast<Affine<F>*>(pts), n, to_mont);
 }
 
+// libff's G::is_well_formed() on affine input: the identity, or Y^2 = X^3 + b (host only; used by the key loader
+// the way groth16_snark.tcc:193-224 checks a proving key after reading it).  *first_bad = n when all points pass.
+template <class F, class Gen>
+int host_points_check(const void* pts, size_t n, int form, size_t* first_bad) {
+  const F b = Gen::coeff_b();
+  const char* src = reinterpret_cast<const char*>(pts);
+  *first_bad = n;
+  for (size_t i = 0; i < n; i++) {
+    Affine<F> p;
+    memcpy(&p, src + i * sizeof(p), sizeof(p));
+    if (p.is_inf()) continue;
+    if (form == ZG_FORM_PLAIN) host_affine_convert(&p, 1, 1);
+    if (F::sqr(p.y) != F::add(F::mul(F::sqr(p.x), p.x), b)) {
+      *first_bad = i;
+      return ZG_OK;
+    }
+  }
+  return ZG_OK;
+}
+
 template <class Fq, class GP>
 struct G1Gen {
   static Affine<Fq> gen() {
@@ -343,6 +363,11 @@ struct G1Gen {
       g.y.v[i] = GP::GY_MONT[i];
     }
     return g;
+  }
+  static Fq coeff_b() {
+    Fq b;
+    for (int i = 0; i < Fq::N; i++) b.v[i] = GP::B_MONT[i];
+    return b;
   }
 };
 template <class Fq2T, class GP>
@@ -356,6 +381,14 @@ struct G2Gen {
       g.y.c1.v[i] = GP::GY_C1_MONT[i];
     }
     return g;
+  }
+  static Fq2T coeff_b() {
+    Fq2T b;
+    for (int i = 0; i < Fq2T::Base::N; i++) {
+      b.c0.v[i] = GP::B_C0_MONT[i];
+      b.c1.v[i] = GP::B_C1_MONT[i];
+    }
+    return b;
   }
 };
 
@@ -373,6 +406,7 @@ struct G2Gen {
                                 &zg::bases_generate<F, FR, GEN>,                                  \
                                 &zg::bases_batch_exp<F, FR, GEN>,                                 \
                                 &zg::host_group_op<F, FR>,                                        \
-                                &zg::host_convert_thunk<F>};                    \
+                                &zg::host_convert_thunk<F>,                                       \
+                                &zg::host_points_check<F, GEN>};                                  \
     return &ops;                                                                                  \
   }

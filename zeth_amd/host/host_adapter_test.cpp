@@ -1,0 +1,346 @@
+// Driver for the tests of the C++ host module (include/libzeth_gpu/): each subcommand exercises one piece of the
+// adapter on files the Python tests prepare and check against the oracle.  Exit codes name the exception class so
+// the error convention can be tested: 10 invalid_argument, 11 length_error, 12 ios_base::failure, 13 runtime_error.
+//
+//   codec CURVE pk_in pk_out assignment_in assignment_out [primary_inputs]     (no GPU)
+//   testdata CURVE out_dir            the fixtures of libzeth/tests/snarks/groth16/groth16_snark_test.cpp:39-171 (no GPU compute)
+//   multi_exp CURVE g1|g2 points scalars out_point
+//   domain CURVE fft|ifft|cosetfft|icosetfft scalars_in scalars_out
+//   lagrange CURVE g1|g2 powers out_points      evaluator_from_lagrange for every single-index factor map (evaluator_from_lagrange_test.cpp:44-65)
+//   prove CURVE pk assignment primary_inputs r_hex s_hex proof_fixed proof_random_1 proof_random_2
+#include <iostream>
+
+#include "../../include/libzeth_gpu/gpu_groth16_snark.hpp"
+
+using namespace libzeth_gpu;
+
+namespace
+{
+
+template<typename ppT> Fr<ppT> neg_fr(uint64_t k)
+{
+    // r - k for small k
+    Fr<ppT> x;
+    uint64_t borrow = k;
+    for (size_t i = 0; i < 4; i++) {
+        const uint64_t limb = ppT::r[i];
+        x.data[i] = limb - borrow;
+        borrow = limb < borrow ? 1 : 0;
+    }
+    return x;
+}
+
+template<typename ppT, typename GroupT> GroupT gen_multiple(const GroupT &gen, const Fr<ppT> &k)
+{
+    GroupT out;
+    check(zg_host_group_op(ppT::curve_id, GroupT::group_id, 1, &gen, k.data, ZG_FORM_PLAIN, &out));
+    return out;
+}
+
+int exception_code(const std::exception &e)
+{
+    if (dynamic_cast<const std::invalid_argument *>(&e)) {
+        return 10;
+    }
+    if (dynamic_cast<const std::length_error *>(&e)) {
+        return 11;
+    }
+    if (dynamic_cast<const std::ios_base::failure *>(&e)) {
+        return 12;
+    }
+    return 13;
+}
+
+template<typename ppT> int cmd_codec(int argc, char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    typename snarkT::proving_key pk;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        snarkT::proving_key_read_bytes(pk, in_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[4]);
+        snarkT::proving_key_write_bytes(pk, out_s);
+    }
+    const size_t primary_inputs = argc > 7 ? std::stoul(argv[7]) : 1;
+    r1cs_primary_input<Fr<ppT>> primary;
+    r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[5]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, primary_inputs, in_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[6]);
+        r1cs_variable_assignment_write_bytes(primary, auxiliary, out_s);
+    }
+    std::cout << "codec ok: " << pk.A_query.size() << " A, " << pk.B_query.values.size() << " B, " << pk.H_query.size() << " H, "
+              << pk.L_query.size() << " L, " << pk.constraint_system.num_constraints() << " constraints, " << primary.size() << "+"
+              << auxiliary.size() << " assignment\n";
+    return 0;
+}
+
+template<typename ppT, typename GroupT> std::vector<GroupT> read_points(const char *path)
+{
+    std::vector<GroupT> pts;
+    std::ifstream in_s = open_binary_input_file(path);
+    group_elements_read_bytes(pts, in_s);
+    return pts;
+}
+
+template<typename ppT> std::vector<Fr<ppT>> read_scalars(const char *path)
+{
+    std::vector<Fr<ppT>> v;
+    std::ifstream in_s = open_binary_input_file(path);
+    r1cs_variable_assignment_read_bytes(v, in_s);
+    return v;
+}
+
+template<typename ppT, typename GroupT> int cmd_multi_exp(char **argv)
+{
+    const std::vector<GroupT> gs = read_points<ppT, GroupT>(argv[4]);
+    const std::vector<Fr<ppT>> fs = read_scalars<ppT>(argv[5]);
+    const GroupT sum = multi_exp<ppT, GroupT>(gs, fs);
+    // the same through resident bases and through the iterator overload must agree
+    resident_bases<ppT, GroupT> rb(gs);
+    if (rb.multi_exp(fs) != sum) {
+        std::cerr << "resident_bases::multi_exp disagrees with multi_exp\n";
+        return 1;
+    }
+    if (!fs.empty() && multi_exp<ppT, GroupT>(gs.begin(), gs.begin() + fs.size(), fs.begin(), fs.end()) != sum) {
+        std::cerr << "iterator multi_exp disagrees with multi_exp\n";
+        return 1;
+    }
+    std::ofstream out_s = open_binary_output_file(argv[6]);
+    group_element_write_bytes(sum, out_s);
+    return 0;
+}
+
+template<typename ppT> int cmd_domain(char **argv)
+{
+    std::vector<Fr<ppT>> a = read_scalars<ppT>(argv[4]);
+    basic_radix2_domain<ppT> domain(a.size());
+    const std::string op = argv[3];
+    const Fr<ppT> g(ppT::multiplicative_generator);
+    if (op == "fft") {
+        domain.FFT(a);
+    } else if (op == "ifft") {
+        domain.iFFT(a);
+    } else if (op == "cosetfft") {
+        domain.cosetFFT(a, g);
+    } else if (op == "icosetfft") {
+        domain.icosetFFT(a, g);
+    } else {
+        throw std::invalid_argument("unknown transform");
+    }
+    std::ofstream out_s = open_binary_output_file(argv[5]);
+    r1cs_variable_assignment_write_bytes(a, out_s);
+    return 0;
+}
+
+template<typename ppT, typename GroupT> int cmd_lagrange(char **argv)
+{
+    const std::vector<GroupT> powers = read_points<ppT, GroupT>(argv[4]);
+    basic_radix2_domain<ppT> domain(powers.size());
+    evaluator_from_lagrange<ppT, GroupT> eval(powers, domain);
+    std::vector<GroupT> out;
+    for (size_t j = 0; j < domain.m; ++j) {
+        std::map<size_t, Fr<ppT>> l_factors;
+        l_factors[j] = Fr<ppT>::one();
+        out.push_back(eval.evaluate_from_lagrange_factors(l_factors));
+    }
+    std::ofstream out_s = open_binary_output_file(argv[5]);
+    group_elements_write_bytes(out, out_s);
+    return 0;
+}
+
+template<size_t n> field_element<n> from_hex(const std::string &hex)
+{
+    field_element<n> v;
+    size_t bit = 0;
+    for (size_t i = hex.size(); i-- > 0 && bit < 64 * n;) {
+        const char c = hex[i];
+        const uint64_t d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : 0;
+        v.data[bit / 64] |= d << (bit % 64);
+        bit += 4;
+    }
+    return v;
+}
+
+template<typename ppT> int cmd_prove(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    typename snarkT::proving_key pk;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        snarkT::proving_key_read_bytes(pk, in_s);
+    }
+    r1cs_primary_input<Fr<ppT>> primary;
+    r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[4]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[5]), in_s);
+    }
+    {
+        device_proving_key<ppT> dpk(pk);
+        const typename snarkT::proof proof = dpk.prove(primary, auxiliary, from_hex<4>(argv[6]), from_hex<4>(argv[7]));
+        std::ofstream out_s = open_binary_output_file(argv[8]);
+        snarkT::proof_write_bytes(proof, out_s);
+    }
+    // the reference's stateless entry point, twice: the second call reuses the resident key; (r, s) are fresh
+    for (int k = 0; k < 2; k++) {
+        const typename snarkT::proof proof = snarkT::generate_proof(pk, primary, auxiliary);
+        std::ofstream out_s = open_binary_output_file(argv[9 + k]);
+        snarkT::proof_write_bytes(proof, out_s);
+    }
+    // wrong sizes are invalid_argument, as a mismatched assignment is in the reference's prover
+    bool threw = false;
+    try {
+        r1cs_auxiliary_input<Fr<ppT>> short_aux(auxiliary.begin(), auxiliary.end() - 1);
+        snarkT::generate_proof(pk, primary, short_aux);
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    if (!threw) {
+        std::cerr << "a short assignment did not raise invalid_argument\n";
+        return 1;
+    }
+    return 0;
+}
+
+// groth16_snark_test.cpp:39-171 (generate_test_data): the hand-made constraint system, proving key and assignment
+template<typename ppT> int cmd_testdata(char **argv)
+{
+    using Field = Fr<ppT>;
+    using snarkT = groth16_snark<ppT>;
+    const std::string dir = argv[3];
+    const std::string curve_name = ppT::name;
+
+    r1cs_constraint_system<Field> cs;
+    linear_combination<Field> cs1_A, cs1_B, cs1_C, cs2_A, cs2_B, cs2_C;
+    cs1_A.add_term(1, 2);
+    cs1_A.add_term(3, 3);
+    cs1_B.add_term(2, 4);
+    cs1_B.add_term(4, 5);
+    cs1_C.add_term(5, 6);
+    cs1_C.add_term(1, 7);
+    cs.add_constraint({cs1_A, cs1_B, cs1_C});
+    cs2_A.add_term(2, 7);
+    cs2_A.add_term(5, 6);
+    cs2_B.add_term(1, 5);
+    cs2_B.add_term(3, 4);
+    cs2_C.add_term(4, 3);
+    cs2_C.add_term(2, 2);
+    cs.add_constraint({cs2_A, cs2_B, cs2_C});
+    cs.primary_input_size = 2;
+    cs.auxiliary_input_size = 3;
+    {
+        std::ofstream out_s = open_binary_output_file(dir + "/groth16_r1cs_" + curve_name);
+        r1cs_write_bytes(cs, out_s);
+    }
+
+    // generators arrive as files written by the test (the library exports no generator constant through the ABI)
+    const G1<ppT> g1 = read_points<ppT, G1<ppT>>((dir + "/g1_one").c_str()).at(0);
+    const G2<ppT> g2 = read_points<ppT, G2<ppT>>((dir + "/g2_one").c_str()).at(0);
+    auto P1 = [&](long k) { return gen_multiple<ppT, G1<ppT>>(g1, k >= 0 ? Field((uint64_t)k) : neg_fr<ppT>((uint64_t)(-k))); };
+    auto P2 = [&](long k) { return gen_multiple<ppT, G2<ppT>>(g2, k >= 0 ? Field((uint64_t)k) : neg_fr<ppT>((uint64_t)(-k))); };
+
+    typename snarkT::proving_key pk;
+    pk.alpha_g1 = P1(1);
+    pk.beta_g1 = P1(-1);
+    pk.beta_g2 = P2(-1);
+    pk.delta_g1 = P1(-2);
+    pk.delta_g2 = P2(-2);
+    pk.A_query = {P1(7), P1(-3), P1(8), P1(-4), P1(9), P1(-5)};
+    const long b_mult[6] = {9, -9, 10, -11, 12, -13};
+    // libsnark's knowledge_commitment_vector(std::vector) constructor indexes the entries 0..n-1 and sets
+    // domain_size_ = n
+    for (size_t i = 0; i < 6; i++) {
+        pk.B_query.indices.push_back(i);
+        pk.B_query.values.push_back({P2(b_mult[i]), P1(b_mult[i])});
+    }
+    pk.B_query.domain_size_ = 6;
+    pk.H_query = {P1(11), P1(-11), P1(12)};
+    pk.L_query = {P1(13), P1(-13), P1(14)};
+    pk.constraint_system = cs;
+    {
+        std::ofstream out_s = open_binary_output_file(dir + "/groth16_proving_key_" + curve_name);
+        snarkT::proving_key_write_bytes(pk, out_s);
+    }
+
+    const r1cs_variable_assignment<Field> assignment = {
+        Field(15), neg_fr<ppT>(15), Field(16), neg_fr<ppT>(16), Field(17), neg_fr<ppT>(17)};
+    {
+        std::ofstream out_s = open_binary_output_file(dir + "/groth16_assignment_" + curve_name);
+        r1cs_variable_assignment_write_bytes(assignment, out_s);
+    }
+
+    // proof round trip in the shape of common_snark_tests.tcc:102-122
+    typename snarkT::proof proof{P1(21), P2(-21), P1(22)};
+    std::stringstream ss;
+    snarkT::proof_write_bytes(proof, ss);
+    typename snarkT::proof back;
+    snarkT::proof_read_bytes(back, ss);
+    if (!(back == proof)) {
+        std::cerr << "proof bytes round trip failed\n";
+        return 1;
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(dir + "/groth16_proof_" + curve_name);
+        snarkT::proof_write_bytes(proof, out_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(dir + "/groth16_proof_" + curve_name + ".json");
+        snarkT::proof_write_json(proof, out_s);
+    }
+    return 0;
+}
+
+template<typename ppT> int run(int argc, char **argv)
+{
+    const std::string cmd = argv[1];
+    if (cmd == "codec" && argc >= 7) {
+        return cmd_codec<ppT>(argc, argv);
+    }
+    if (cmd == "testdata" && argc >= 4) {
+        return cmd_testdata<ppT>(argv);
+    }
+    if (cmd == "multi_exp" && argc >= 7) {
+        return std::string(argv[3]) == "g1" ? cmd_multi_exp<ppT, G1<ppT>>(argv) : cmd_multi_exp<ppT, G2<ppT>>(argv);
+    }
+    if (cmd == "domain" && argc >= 6) {
+        return cmd_domain<ppT>(argv);
+    }
+    if (cmd == "lagrange" && argc >= 6) {
+        return std::string(argv[3]) == "g1" ? cmd_lagrange<ppT, G1<ppT>>(argv) : cmd_lagrange<ppT, G2<ppT>>(argv);
+    }
+    if (cmd == "prove" && argc >= 11) {
+        return cmd_prove<ppT>(argv);
+    }
+    std::cerr << "usage: see the head of host_adapter_test.cpp\n";
+    return 2;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) {
+        std::cerr << "usage: see the head of host_adapter_test.cpp\n";
+        return 2;
+    }
+    try {
+        const std::string curve = argv[2];
+        if (curve == "alt-bn128") {
+            return run<alt_bn128_pp>(argc, argv);
+        }
+        if (curve == "bls12-377") {
+            return run<bls12_377_pp>(argc, argv);
+        }
+        std::cerr << "unrecognized curve\n";
+        return 2;
+    } catch (const std::exception &e) {
+        std::cerr << "exception: " << e.what() << "\n";
+        return exception_code(e);
+    }
+}
