@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
-#include "curve.cuh"
+#include "msm.cuh"
 
 using namespace zg;
 using F = Bn254Fq;
@@ -48,10 +48,17 @@ __global__ void __launch_bounds__(256) k_lin(const F* in, F* out, int iters, Clk
   if (blockIdx.x == 0 && threadIdx.x == 0) *clk = Clk{c1 - c0, w1 - w0};
 }
 
-// the mixed addition without its exceptional-case branches (straight-line general case)
+// the mixed addition without its exceptional-case branches (straight-line general case).  DESYNC: every wave first
+// runs a different number of products so that the waves of a CU sit at different places of the loop body (as they do
+// in k_accum, where memory latency spreads them out) instead of fetching the same instructions together.
+template <int DESYNC>
 __global__ void __launch_bounds__(256) k_madd_straight(const Affine<F>* in, XYZZ<F>* out, int iters, Clk* clk) {
   Affine<F> p = in[threadIdx.x & 7];
   XYZZ<F> acc = XYZZ<F>::from_affine(in[(threadIdx.x + 1) & 7]);
+  if (DESYNC) {
+    const int skew = (int)((blockIdx.x * 4 + threadIdx.x / 64) * 2654435761u >> 24) % 53;
+    for (int i = 0; i < skew; i++) p.x = F::mul(p.x, p.y);
+  }
   unsigned long long c0 = clock64(), w0 = wall_clock64();
   for (int i = 0; i < iters; i++) {
     F U2 = F::mul(p.x, acc.zz);
@@ -111,6 +118,59 @@ static void run(const char* name, K kern, int blocks, int iters, double ops_per_
          "\"simd_cycles_per_wave_op\": %.0f}\n", name, blocks, waves_per_simd, best, mhz, cyc);
 }
 
+// k_accum itself on fabricated inputs: every unit `len` entries long, entries uniformly random over `nbases` points
+static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbases, const Affine<F>* dp8) {
+  const size_t lanes = (size_t)blocks * 256;
+  std::vector<UnitDesc> hu(lanes);
+  std::vector<uint32_t> hord(lanes), hsorted(lanes * len), hw(2);
+  uint64_t x = 88172645463325252ull;
+  for (size_t i = 0; i < lanes; i++) {
+    hu[i] = UnitDesc{(uint64_t)i * len, len, (uint32_t)i};
+    hord[i] = (uint32_t)i;
+  }
+  for (auto& e : hsorted) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    e = (uint32_t)(x % nbases) | ((x >> 40) & 1 ? 0x80000000u : 0u);
+  }
+  hw[0] = (uint32_t)lanes;
+  std::vector<Affine<F>> hb(nbases);
+  Affine<F> h8[8];
+  hipMemcpy(h8, dp8, sizeof(h8), hipMemcpyDeviceToHost);
+  {
+    // distinct points (i + 1) G for the first 4096, repeated with a stride that keeps neighbours distinct
+    const uint32_t distinct = nbases < 4096 ? nbases : 4096;
+    XYZZ<F> t = XYZZ<F>::from_affine(h8[0]);
+    for (uint32_t i = 0; i < distinct; i++) {
+      hb[i] = xyzz_to_affine(t);
+      xyzz_madd(t, h8[0]);
+    }
+    for (uint32_t i = distinct; i < nbases; i++) hb[i] = hb[(i * 2654435761u) % distinct];
+  }
+  UnitDesc* du; uint32_t *dord, *dsorted, *dw; Affine<F>* db; XYZZ<F>* dpart;
+  hipMalloc(&du, hu.size() * sizeof(UnitDesc)); hipMalloc(&dord, lanes * 4); hipMalloc(&dsorted, hsorted.size() * 4);
+  hipMalloc(&dw, 8); hipMalloc(&db, hb.size() * sizeof(Affine<F>)); hipMalloc(&dpart, lanes * sizeof(XYZZ<F>));
+  hipMemcpy(du, hu.data(), hu.size() * sizeof(UnitDesc), hipMemcpyHostToDevice);
+  hipMemcpy(dord, hord.data(), lanes * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dsorted, hsorted.data(), hsorted.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dw, hw.data(), 8, hipMemcpyHostToDevice);
+  hipMemcpy(db, hb.data(), hb.size() * sizeof(Affine<F>), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int r = 0; r < 3; r++) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_accum<F>), dim3(blocks, 1), dim3(256), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  double wave_ops = (double)blocks * 4 * len;
+  printf("{\"case\": \"%s\", \"blocks\": %d, \"len\": %u, \"nbases\": %u, \"ms\": %.3f, \"simd_cycles_per_wave_op_at_2.4GHz\": %.0f}\n",
+         name, blocks, len, nbases, best, best * 1e-3 * 2.4e9 * 1024.0 / wave_ops);
+  hipFree(du); hipFree(dord); hipFree(dsorted); hipFree(dw); hipFree(db); hipFree(dpart);
+}
+
 int main() {
   F hin[8];
   for (int i = 0; i < 8; i++) {
@@ -145,7 +205,13 @@ int main() {
   for (int wps : {1, 2, 3, 4, 6, 8}) run("mul_chain1", k_mul<1>, 256 * wps, 4096, 1.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 2, 3, 4}) run("mul_chain2", k_mul<2>, 256 * wps, 2048, 2.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 2, 3, 6}) run("madd", k_madd, 256 * wps, 512, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
-  for (int wps : {1, 3}) run("madd_straight", k_madd_straight, 256 * wps, 512, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
+  for (int wps : {1, 3}) run("madd_straight", k_madd_straight<0>, 256 * wps, 512, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
+  // sustained load (~100 ms per launch): does the shader clock hold?
+  run("madd_straight_desync", k_madd_straight<1>, 512, 512 * 16, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
+  run("madd_straight_long", k_madd_straight<0>, 512, 512 * 8, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
+  run_accum("k_accum_synth", 512, 512, 1u << 12, dp);
+  run_accum("k_accum_synth", 2048, 512, 1u << 12, dp);
+  run_accum("k_accum_synth", 2048, 512, 1u << 22, dp);
   for (int wps : {1, 3}) run("sub", k_lin<0>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("add", k_lin<1>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("cneg", k_lin<2>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);

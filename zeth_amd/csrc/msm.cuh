@@ -18,6 +18,7 @@
 // Host tail: Horner over the W window sums (c doublings each) and normalisation to affine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -85,6 +86,10 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   size_t L = ((size_t)p.W * n) >> 18;
   if (L < 32) L = 32;
   if (L > 1024) L = 1024;
+  if (const char* e = getenv("ZG_MSM_UNIT_LEN")) {  // tuning knob
+    size_t v = strtoul(e, nullptr, 0);
+    if (v >= 1 && v <= 1024) L = v;
+  }
   p.L = (uint32_t)L;
   p.cap = p.nb + (uint32_t)(n / L) + 1;
   uint32_t nchunk = (uint32_t)((n + (1u << 16) - 1) >> 16);  // >= 64K entries per chunk
@@ -196,12 +201,16 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t* __restrict__ wunits /* [W] unit totals, [W] = max units per bucket */,
                                                 uint32_t nhi /* partitions of 256 buckets (0: single-level sort) */,
                                                 uint32_t* __restrict__ cursor1 /* [W][nhi] */,
-                                                uint32_t* __restrict__ pstart /* [W][nhi + 1] */) {
-  __shared__ uint32_t sa[1024], sb[1024];
+                                                uint32_t* __restrict__ pstart /* [W][nhi + 1] */,
+                                                uint32_t* __restrict__ lencur /* [W][1024]: first slot of each unit length */) {
+  __shared__ uint32_t sa[1024], sb[1024], lh[1025];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   const uint32_t per = (nb + 1023) / 1024;
   const uint32_t b0 = tid * per;
   uint32_t ca = 0, cb = 0;
+  lh[tid] = 0;
+  if (tid == 0) lh[1024] = 0;
+  __syncthreads();
   for (uint32_t j = 0; j < per; j++) {
     uint32_t b = b0 + j;
     if (b < nb) {
@@ -209,7 +218,26 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
       ca += v;
       cb += (v + L - 1) / L;
       if (v > L) atomicMax(&wunits[gridDim.x], (v + L - 1) / L);
+      // histogram of unit lengths (1..L <= 1024): v / L full units and one of v % L
+      if (v >= L) atomicAdd(&lh[L], v / L);
+      if (v % L) atomicAdd(&lh[v % L], 1u);
     }
+  }
+  __syncthreads();
+  // units are handed to the accumulation kernel longest first (a wave runs as long as its longest lane): slot
+  // ranges per length, descending, from an exclusive scan over the reversed histogram
+  {
+    const uint32_t own = lh[1024 - tid];
+    sa[tid] = own;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      uint32_t x = tid >= off ? sa[tid - off] : 0;
+      __syncthreads();
+      sa[tid] += x;
+      __syncthreads();
+    }
+    lencur[(size_t)w * 1024 + (1023 - tid)] = sa[tid] - own;  // index = length - 1
+    __syncthreads();
   }
   sa[tid] = ca;
   sb[tid] = cb;
@@ -385,18 +413,27 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
 
 static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
                                                 const uint32_t* __restrict__ ufirst, uint32_t nb, uint32_t W, uint32_t L,
-                                                UnitDesc* __restrict__ units) {
+                                                uint32_t cap, UnitDesc* __restrict__ units, uint32_t* __restrict__ lencur,
+                                                uint32_t* __restrict__ order /* [W][cap]: unit ids, longest first */) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)nb * W) return;
+  const uint32_t w = (uint32_t)(g / nb);
   uint32_t v = cnt[g];
   uint32_t u = ufirst[g];
   uint64_t start = boff[g];
-  while (v) {
-    uint32_t len = v < L ? v : L;
-    units[u] = UnitDesc{start, len, (uint32_t)g};
-    u++;
-    start += len;
-    v -= len;
+  // one slot claim for all full-length units of the bucket (a 0/1-heavy witness puts thousands into one bucket)
+  const uint32_t full = v / L, rem = v % L;
+  uint32_t* slots = order + (size_t)w * cap;
+  if (full) {
+    const uint32_t pos = atomicAdd(&lencur[(size_t)w * 1024 + (L - 1)], full);
+    for (uint32_t k = 0; k < full; k++) {
+      units[u + k] = UnitDesc{start + (uint64_t)k * L, L, (uint32_t)g};
+      slots[pos + k] = u + k;
+    }
+  }
+  if (rem) {
+    units[u + full] = UnitDesc{start + (uint64_t)full * L, rem, (uint32_t)g};
+    slots[atomicAdd(&lencur[(size_t)w * 1024 + (rem - 1)], 1u)] = u + full;
   }
 }
 
@@ -416,29 +453,66 @@ ZG_HD Affine<F> load_affine(const Affine<F>* __restrict__ bases, size_t idx) {
   return u.p;
 }
 
+// acc += p for the lanes of one wave.  The general addition (xyzz_madd) carries four exceptional cases; as divergent
+// branches they cost ~2,500 of its ~15,100 cycles per wave (tools/bench_madd.hip: the straight-line formula alone is
+// ~12,600) in exec-mask bookkeeping and register copies at the joins.  Here the common case is one straight line and
+// the exceptional cases are taken by the WHOLE wave (ballot), which is rare: an identity base, an accumulator that
+// cancelled to the identity, or an addition of equal / opposite points.
+template <class F>
+__device__ __forceinline__ void xyzz_madd_wave(XYZZ<F>& acc, const Affine<F>& p) {
+  const F U2 = F::mul(p.x, acc.zz);
+  const F S2 = F::mul(p.y, acc.zzz);
+  const F Pd = F::sub(U2, acc.x);
+  const F R = F::sub(S2, acc.y);
+  const int exceptional = (int)p.is_inf() | (int)acc.is_inf() | (int)Pd.is_zero();
+  if (__ballot(exceptional) != 0ull) {
+    xyzz_madd(acc, p);
+    return;
+  }
+  const F PP = F::sqr(Pd);
+  const F PPP = F::mul(Pd, PP);
+  const F Q = F::mul(acc.x, PP);
+  const F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+  acc.y = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+  acc.x = X3;
+  acc.zz = F::mul(acc.zz, PP);
+  acc.zzz = F::mul(acc.zzz, PPP);
+}
+
 #ifndef ZG_ACCUM_MIN_WAVES
 #define ZG_ACCUM_MIN_WAVES 1
 #endif
 template <class F>
 __global__ void __launch_bounds__(256, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
-                                                uint32_t cap, const uint32_t* __restrict__ sorted,
-                                                const Affine<F>* __restrict__ bases, XYZZ<F>* __restrict__ part) {
-  const uint32_t w = blockIdx.y;
+                                                uint32_t cap, const uint32_t* __restrict__ order,
+                                                const uint32_t* __restrict__ sorted,
+                                                const Affine<F>* __restrict__ bases, XYZZ<F>* __restrict__ part,
+                                                const uint32_t idx_mask /* 0x7FFFFFFF: strips the sign bit */) {
+  // Workgroups are dispatched in blockIdx order.  The top window comes first: its digits cover fewer values (the scalar's
+  // leading bits), so its buckets -- and units -- are the longest, and a long unit that starts late is the kernel's tail.
+  const uint32_t w = gridDim.y - 1 - blockIdx.y;
   const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
   if (ul >= wunits[w]) return;
-  const size_t u = (size_t)w * cap + ul;
+  const size_t u = order[(size_t)w * cap + ul];  // longest units first; the lanes of a wave get (nearly) equal lengths
   const UnitDesc d = units[u];
   const uint32_t* __restrict__ ent = sorted + d.start;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  const uint32_t last = d.len - 1;
+  // software pipeline: the base of entry t + 1 and the index of entry t + 2 are in flight while entry t is added
   uint32_t e = ent[0];
-  Affine<F> p = load_affine(bases, e & 0x7FFFFFFFu);
-  for (uint32_t t = 0; t < d.len; t++) {
-    // prefetch the next entry's base while this one is being added
-    uint32_t en = (t + 1 < d.len) ? ent[t + 1] : e;
-    Affine<F> pn = load_affine(bases, en & 0x7FFFFFFFu);
+  uint32_t en = ent[last < 1 ? last : 1];
+  Affine<F> p = load_affine(bases, e & idx_mask);
+  p.y = F::cneg(p.y, (e >> 31) != 0);
+  XYZZ<F> acc = XYZZ<F>::from_affine(p);
+  p = load_affine(bases, en & idx_mask);
+  e = en;
+  en = ent[last < 2 ? last : 2];
+  for (uint32_t t = 1; t <= last; t++) {
+    const Affine<F> pn = load_affine(bases, en & idx_mask);
+    const uint32_t en2 = ent[t + 2 <= last ? t + 2 : last];
     p.y = F::cneg(p.y, (e >> 31) != 0);
-    xyzz_madd(acc, p);
+    xyzz_madd_wave(acc, p);
     e = en;
+    en = en2;
     p = pn;
   }
   part[u] = acc;

@@ -1,6 +1,7 @@
 // Host driver for the MSM pipeline plus base-point set-up kernels, generic over the group.
 // One translation unit per (curve, group) instantiates this through ZG_DEFINE_GROUP_OPS.
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.cuh"
@@ -28,6 +29,16 @@ __global__ void __launch_bounds__(256) k_to_mont(B* __restrict__ elems, size_t c
 }
 
 static constexpr uint32_t GEN_CHUNK = 64;
+
+// Measurement knob (wrong results by design): ZG_DEBUG_BASE_MASK=0xffff makes every gather of the accumulation
+// kernel hit the first 2^16 bases, which separates its arithmetic time from its memory time.
+inline uint32_t zg_debug_base_mask() {
+  static const uint32_t mask = [] {
+    const char* e = getenv("ZG_DEBUG_BASE_MASK");
+    return e ? (uint32_t)strtoul(e, nullptr, 0) & 0x7FFFFFFFu : 0x7FFFFFFFu;
+  }();
+  return mask;
+}
 
 // lane j: points [j*64, j*64+64): start (t0 + j*64*d) * G by double-and-add, then repeated + D
 template <class F, class Fr>
@@ -161,7 +172,8 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   const uint32_t nhi = p.nb >= 512 ? (p.nb >> 8) : 0;  // two-level sort when a window has >= 512 buckets
   size_t need = (nhi ? zg_ctx::ws_round(WN * 4) + zg_ctx::ws_round(WN) + 2 * zg_ctx::ws_round((size_t)p.W * (nhi + 1) * 4) : 0) +
                 zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
-                zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) +
+                zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) + zg_ctx::ws_round(WC * 4) +
+                zg_ctx::ws_round((size_t)p.W * 1024 * 4) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
   ZG_TRY(ctx->ws_reserve(need));
   int16_t* dig = ctx->ws_take<int16_t>(WN);
@@ -172,6 +184,8 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   uint32_t* ufirst = ctx->ws_take<uint32_t>(WB);
   uint32_t* wunits = ctx->ws_take<uint32_t>(p.W + 1 + 64);  // [W] unit totals, [W] max units per bucket, then 64 dense-scalar counters
   UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
+  uint32_t* order = ctx->ws_take<uint32_t>(WC);
+  uint32_t* lencur = ctx->ws_take<uint32_t>((size_t)p.W * 1024);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
   XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)p.W * p.T);
   uint32_t *mid_ent = nullptr, *cursor1 = nullptr, *pstart = nullptr;
@@ -183,7 +197,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     pstart = ctx->ws_take<uint32_t>((size_t)p.W * (nhi + 1));
     if (!mid_ent || !mid_lo || !cursor1 || !pstart) return ZG_ERR_OUT_OF_MEMORY;
   }
-  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !wunits || !units || !part || !seg)
+  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !wunits || !units || !order || !lencur || !part || !seg)
     return ZG_ERR_OUT_OF_MEMORY;
 
   hipStream_t st = ctx->stream;
@@ -204,7 +218,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
   ctx->mark("scan");
   hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits, nhi,
-                     cursor1, pstart);
+                     cursor1, pstart, lencur);
   ctx->mark("scatter");
   if (nhi) {
     hipLaunchKernelGGL(k_scatter_hi, dim3((unsigned)((n + SORT_TILE1 - 1) / SORT_TILE1), p.W), dim3(1024), 0, st, dig, n,
@@ -219,10 +233,10 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   }
   ctx->mark("units");
   hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, p.nb,
-                     (uint32_t)p.W, p.L, units);
+                     (uint32_t)p.W, p.L, p.cap, units, lencur, order);
   ctx->mark("accum");
-  hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, p.cap, sorted,
-                     d_bases, part);
+  hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, p.cap, order, sorted,
+                     d_bases, part, zg_debug_base_mask());
   ctx->mark("combine");
   for (uint32_t s = 1; s < (uint32_t)((n + p.L - 1) / p.L); s <<= 1)
     hipLaunchKernelGGL((k_combine<F>), dim3((p.cap + 1023) / 1024, p.W), dim3(1024), 0, st, units, wunits, (uint32_t)p.W,
