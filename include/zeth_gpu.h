@@ -158,6 +158,27 @@ int zg_witness_map(zg_pk* pk, const void* primary, size_t n_primary, const void*
  * exported so tests can pin it without a GPU.  op: 0 = a + b, 1 = k * a (k: Fr plain 32 B in `b`) */
 int zg_host_group_op(int curve, int group, int op, const void* a_affine, const void* b, int form, void* out_affine);
 
+/* ---- group-element kernels of the SRS ceremony (host arrays in and out; set-up time, not the proving path) ---- */
+
+/* In-place radix-2 transform over 2^log_n GROUP elements (affine, natural order): out_j = sum_i w^(i j) P_i with
+ * w = omega (inverse = 0), or w = omega^-1 followed by the scaling by n^-1 (inverse = 1).  inverse = 1 is
+ * compute_lagrange_from_powers = libfqfft::_basic_radix2_FFT<Fr, Gr>(powers, omega_inv) then n_inv * a
+ * (libzeth/mpc/groth16/powersoftau_utils.tcc:125-134), the body of powersoftau_compute_lagrange_evaluations
+ * (:830-902): from [tau^i] to [L_j(tau)]. */
+int zg_group_fft(zg_ctx* ctx, int curve, int group, void* points, unsigned log_n, int inverse, int form);
+
+/* P_i <- k * P_i for one scalar k (Fr, plain, 32 B): the delta_j^-1 update of L_g1 and H_g1 in
+ * srs_mpc_phase2_update_accumulator (libzeth/mpc/groth16/phase2.tcc:447-470). */
+int zg_group_scale(zg_ctx* ctx, int curve, int group, void* points, size_t n, const void* k, int form);
+
+/* out_j = sum over the sparse row j of coeff * points[col] (CSR; coeff: Fr, plain): the per-variable evaluations
+ * A_j, B_j, C_j at x from the Lagrange evaluations in mpc_compute_linearcombination
+ * (libzeth/mpc/groth16/mpc_utils.tcc:187-242; rows = qap.{A,B,C}_in_Lagrange_basis[j]).  col >= n_points ->
+ * ZG_ERR_INVALID_ARGUMENT. */
+int zg_group_sparse_combine(zg_ctx* ctx, int curve, int group, const void* points, size_t n_points,
+                            const uint64_t* row_ptr, const uint32_t* col, const void* coeff, size_t n_rows, int form,
+                            void* out_points);
+
 /* libff's G::is_well_formed() over n affine points (the identity, or Y^2 = X^3 + b), on the host: what
  * groth16_snark<ppT>::proving_key_read_bytes runs on a key it has just read
  * (libzeth/snarks/groth16/groth16_snark.tcc:145-147, 193-213).  *first_bad = n when every point passes, else the

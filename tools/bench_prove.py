@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", default="alt-bn128")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--constraints", type=int, default=0, help="exact constraint count (overrides --scale)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
@@ -35,7 +36,7 @@ def measure(args, ctx=None):
     cid = 0 if args.curve == "alt-bn128" else 1
     info = CURVE_INFO[cid]
     t = time.time()
-    cs, primary, aux = joinsplit_shaped(info.r, seed=1, scale=args.scale)
+    cs, primary, aux = joinsplit_shaped(info.r, seed=1, scale=args.scale, constraints=getattr(args, "constraints", 0))
     t_circ = time.time() - t
     if ctx is None:
         ctx = zeth_amd.Context(0)

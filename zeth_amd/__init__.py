@@ -15,6 +15,9 @@ from .lib import (  # noqa: F401
     Groth16Snark,
     ProvingKey,
     ZethGpuError,
+    group_fft,
+    group_scale,
+    group_sparse_combine,
     host_group_op,
     load_library,
 )

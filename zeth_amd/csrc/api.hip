@@ -400,6 +400,31 @@ int zg_host_group_op(int curve, int group, int op, const void* a, const void* b,
 }
 
 
+int zg_group_fft(zg_ctx* ctx, int curve, int group, void* points, unsigned log_n, int inverse, int form) {
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ctx || !ops || !points || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  return ops->group_fft(ctx, curve, points, log_n, inverse != 0, form);
+}
+
+int zg_group_scale(zg_ctx* ctx, int curve, int group, void* points, size_t n, const void* k, int form) {
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ctx || !ops || (n && !points) || !k || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  return ops->group_scale(ctx, points, n, (const uint32_t*)k, form);
+}
+
+int zg_group_sparse_combine(zg_ctx* ctx, int curve, int group, const void* points, size_t n_points, const uint64_t* row_ptr,
+                            const uint32_t* col, const void* coeff, size_t n_rows, int form, void* out_points) {
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ctx || !ops || (n_points && !points) || (n_rows && (!row_ptr || !out_points)) ||
+      (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT))
+    return ZG_ERR_INVALID_ARGUMENT;
+  if (n_rows && row_ptr[n_rows] && (!col || !coeff)) return ZG_ERR_INVALID_ARGUMENT;
+  ZG_HIP(hipSetDevice(ctx->device));
+  return ops->group_combine(ctx, points, n_points, row_ptr, col, coeff, n_rows, form, out_points);
+}
+
 int zg_host_points_check(int curve, int group, const void* points, size_t n, int form, size_t* first_bad) {
   const GroupOps* ops = zg_group_ops(curve, group);
   if (!ops || (n && !points) || !first_bad || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;

@@ -130,6 +130,11 @@ struct GroupOps {
   void (*host_convert)(void* pts, size_t n, int to_mont);
   // host-side curve-equation check of n affine points; *first_bad = n when all pass
   int (*points_check)(const void* pts, size_t n, int form, size_t* first_bad);
+  // ceremony kernels (group_ops.cuh); host arrays in and out
+  int (*group_fft)(zg_ctx*, int curve, void* points, unsigned log_n, int inverse, int form);
+  int (*group_scale)(zg_ctx*, void* points, size_t n, const uint32_t* k_plain, int form);
+  int (*group_combine)(zg_ctx*, const void* points, size_t n_points, const uint64_t* row_ptr, const uint32_t* col,
+                       const void* coeff_plain, size_t n_rows, int form, void* out_points);
 };
 
 const GroupOps* zg_group_ops(int curve, int group);

@@ -421,6 +421,9 @@ struct G2Gen {
                                 &zg::bases_batch_exp<F, FR, GEN>,                                 \
                                 &zg::host_group_op<F, FR>,                                        \
                                 &zg::host_convert_thunk<F>,                                       \
-                                &zg::host_points_check<F, GEN>};                                  \
+                                &zg::host_points_check<F, GEN>,                                   \
+                                &zg::group_fft<F, FR>,                                            \
+                                &zg::group_scale<F, FR>,                                          \
+                                &zg::group_combine<F, FR>};                                       \
     return &ops;                                                                                  \
   }

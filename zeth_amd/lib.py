@@ -86,6 +86,10 @@ def load_library():
     L.zg_prove.argtypes = [vp, vp, sz, vp, sz, ci, vp, vp, ci, vp]
     L.zg_witness_map.argtypes = [vp, vp, sz, vp, sz, ci, ci, vp]
     L.zg_host_group_op.argtypes = [ci, ci, ci, vp, vp, ci, vp]
+    L.zg_host_points_check.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(sz)]
+    L.zg_group_fft.argtypes = [vp, ci, ci, vp, ctypes.c_uint, ci, ci]
+    L.zg_group_scale.argtypes = [vp, ci, ci, vp, sz, vp, ci]
+    L.zg_group_sparse_combine.argtypes = [vp, ci, ci, vp, sz, vp, vp, vp, sz, ci, vp]
     _LIB = L
     return L
 
@@ -448,3 +452,37 @@ def host_group_op(curve: int, group: int, op: str, a, b):
         code = 1
     _check(L.zg_host_group_op(curve, group, code, abuf, bbuf, FORM_PLAIN, out))
     return decode_point(curve, group, out.raw)
+
+
+def _decode_points(curve: int, group: int, raw: bytes, n: int) -> list:
+    ab = affine_bytes(curve, group)
+    return [decode_point(curve, group, raw[i * ab : (i + 1) * ab]) for i in range(n)]
+
+
+def group_fft(ctx: Context, curve: int, group: int, points: Sequence, inverse: bool = False) -> list:
+    """Radix-2 transform over group elements (libfqfft::_basic_radix2_FFT<Fr, Gr>); inverse=True also scales by 1/n,
+    i.e. compute_lagrange_from_powers (powersoftau_utils.tcc:125-134)."""
+    n = len(points)
+    if n < 1 or n & (n - 1):
+        raise ValueError("group_fft: the number of points must be a power of two")
+    buf = ctypes.create_string_buffer(b"".join(encode_point(curve, group, P) for P in points), n * affine_bytes(curve, group))
+    _check(ctx._L.zg_group_fft(ctx._h, curve, group, buf, n.bit_length() - 1, int(inverse), FORM_PLAIN))
+    return _decode_points(curve, group, buf.raw, n)
+
+
+def group_scale(ctx: Context, curve: int, group: int, points: Sequence, k: int) -> list:
+    """[k * P for P in points] (phase2.tcc:447-470)."""
+    n = len(points)
+    buf = ctypes.create_string_buffer(b"".join(encode_point(curve, group, P) for P in points), max(1, n * affine_bytes(curve, group)))
+    _check(ctx._L.zg_group_scale(ctx._h, curve, group, buf, n, int_to_le(k, 32), FORM_PLAIN))
+    return _decode_points(curve, group, buf.raw, n)
+
+
+def group_sparse_combine(ctx: Context, curve: int, group: int, points: Sequence, rows: Sequence, r: int) -> list:
+    """rows: list of {point index: coefficient}; -> [sum coeff * points[idx] for each row] (mpc_utils.tcc:187-242)."""
+    rp, col, val = csr_from_rows(rows, r)
+    n = len(points)
+    pbuf = ctypes.create_string_buffer(b"".join(encode_point(curve, group, P) for P in points), max(1, n * affine_bytes(curve, group)))
+    out = ctypes.create_string_buffer(max(1, len(rows) * affine_bytes(curve, group)))
+    _check(ctx._L.zg_group_sparse_combine(ctx._h, curve, group, pbuf, n, rp, col, val, len(rows), FORM_PLAIN, out))
+    return _decode_points(curve, group, out.raw, len(rows))

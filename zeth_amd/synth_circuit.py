@@ -10,14 +10,19 @@ import numpy as np
 from .keygen import CsrR1cs
 
 
-def joinsplit_shaped(r: int, seed: int = 1, scale: float = 1.0):
-    """-> (CsrR1cs, primary, aux).  scale < 1 shrinks every count proportionally (tests)."""
+def joinsplit_shaped(r: int, seed: int = 1, scale: float = 1.0, constraints: int = 0):
+    """-> (CsrR1cs, primary, aux).  scale < 1 shrinks every count proportionally (tests); `constraints` asks for an
+    exact constraint count instead (BASELINE.json configs[3]: 2^22 - 2, so that the domain is 2^22)."""
     rng = np.random.default_rng(seed)
+    if constraints:
+        scale = (constraints - 1) / 436_000.0
     n_bool_checked = int(230_000 * scale)    # free bits with a booleanity constraint x (1 - x) = 0
     n_bool_free = int(110_000 * scale)       # bits whose booleanity is implied elsewhere
     n_and = int(160_000 * scale)             # z = x AND y  (x * y = z)
     n_chain = int(43_000 * scale)            # s' = (s + k)^2, field valued
     n_pack = max(1, int(3_000 * scale))      # sum 2^i b_i = word
+    if constraints:
+        n_bool_checked += constraints - (n_bool_checked + n_and + n_chain + n_pack + 1)
     n_free = n_bool_checked + n_bool_free
     # variable indices (0 is the constant one, 1 the public input)
     v_bits = 2 + np.arange(n_free)
