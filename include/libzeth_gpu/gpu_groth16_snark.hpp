@@ -526,6 +526,34 @@ private:
     const basic_radix2_domain<ppT> &domain_;
 };
 
+// ---- ceremony kernels (libzeth/mpc/groth16) ----
+
+/// compute_lagrange_from_powers (powersoftau_utils.tcc:125-134): [x^i] -> [L_j(x)] in place, i.e.
+/// libfqfft::_basic_radix2_FFT<Fr, Gr>(powers, omega_inv) followed by the scaling by n^-1; the body of
+/// powersoftau_compute_lagrange_evaluations (:830-902), which rejects sizes that are not a power of two.
+template<typename ppT, typename GroupT> void compute_lagrange_from_powers(std::vector<GroupT> &powers)
+{
+    const size_t n = powers.size();
+    if (n == 0 || (n & (n - 1)) != 0) {
+        throw std::invalid_argument("non-pow-2 domain");
+    }
+    unsigned log_n = 0;
+    while ((size_t(1) << log_n) < n) {
+        log_n++;
+    }
+    device_context &dc = device_context::get();
+    std::lock_guard<std::mutex> lock(dc.mutex());
+    check(zg_group_fft(dc.ctx(), ppT::curve_id, GroupT::group_id, powers.data(), log_n, 1, ZG_FORM_PLAIN));
+}
+
+/// a <- k * a for every element: the delta_j^-1 update of L_g1 / H_g1 (phase2.tcc:447-470)
+template<typename ppT, typename GroupT> void batch_scalar_mul(std::vector<GroupT> &points, const Fr<ppT> &k)
+{
+    device_context &dc = device_context::get();
+    std::lock_guard<std::mutex> lock(dc.mutex());
+    check(zg_group_scale(dc.ctx(), ppT::curve_id, GroupT::group_id, points.data(), points.size(), k.data, ZG_FORM_PLAIN));
+}
+
 } // namespace libzeth_gpu
 
 #endif // LIBZETH_GPU_GROTH16_SNARK_HPP

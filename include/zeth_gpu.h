@@ -138,6 +138,12 @@ typedef struct {
  * prover_server/prover_server.cpp:449-493).  Size mismatches -> ZG_ERR_INVALID_ARGUMENT. */
 int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out);
 void zg_pk_free(zg_pk* pk);
+/* A second prover over the same resident key, for another calling thread: it shares the key's bases and matrices
+ * in HBM and owns its per-proof scratch, its streams and a context of its own, so zg_prove on the clone may overlap
+ * zg_prove on the original (and on other clones).  This is how several proofs are kept in flight on one device
+ * (BASELINE configs[4]; prover_server shares one key between its handlers, prover_server.cpp:51,451).  Free every
+ * clone before the key it was cloned from. */
+int zg_pk_clone(zg_pk* pk, zg_pk** out);
 int zg_pk_domain_size(const zg_pk* pk, size_t* m);
 
 /* Replaces groth16_snark<ppT>::generate_proof(pk, primary_input, auxiliary_input)

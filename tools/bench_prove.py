@@ -10,6 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("ZETH_GPU_HW_QUEUES", "32")  # see bench.py; before HIP initialises
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
@@ -21,6 +22,7 @@ def main():
     ap.add_argument("--constraints", type=int, default=0, help="exact constraint count (overrides --scale)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--in-flight", type=int, default=4, help="proofs kept in flight on the device for the throughput figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -66,6 +68,49 @@ def measure(args, ctx=None):
     raw = out.raw
     proof = (zl.decode_point(cid, 1, raw[: 2 * n]), zl.decode_point(cid, 2, raw[2 * n: 6 * n]), zl.decode_point(cid, 1, raw[6 * n:]))
     times.sort()
+    # Throughput with K proofs in flight (BASELINE configs[4], one device's share): K host threads, each with a
+    # clone of the resident key (shared bases, own scratch and streams), every proof checked against the serial one.
+    inflight = {}
+    K = int(getattr(args, "in_flight", 0) or 0)
+    if K > 1:
+        import threading
+
+        clones = [dpk] + [dpk.clone() for _ in range(K - 1)]
+        per_thread = max(4, args.steps)
+        outs = [ctypes.create_string_buffer(8 * n) for _ in range(K)]
+        errs = []
+        barrier = threading.Barrier(K + 1)
+
+        def worker(k):
+            try:
+                zl._check(ctx._L.zg_prove(clones[k]._h, pb, len(primary), ab, len(aux), zl.FORM_PLAIN, rb, sb, zl.FORM_PLAIN, outs[k]))
+                barrier.wait()
+                for _ in range(per_thread):
+                    zl._check(ctx._L.zg_prove(clones[k]._h, pb, len(primary), ab, len(aux), zl.FORM_PLAIN, rb, sb, zl.FORM_PLAIN, outs[k]))
+                    if outs[k].raw != raw:
+                        errs.append("thread %d: proof differs from the serial proof" % k)
+                        break
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+                try:
+                    barrier.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
+        for th in threads:
+            th.start()
+        barrier.wait()
+        t0 = time.perf_counter()
+        for th in threads:
+            th.join()
+        wall = time.perf_counter() - t0
+        for c in clones[1:]:
+            c.free()
+        if errs:
+            raise SystemExit("in-flight proving failed: " + "; ".join(errs))
+        inflight = {"proofs_in_flight": K, "proofs": K * per_thread, "wall_ms": wall * 1e3,
+                    "proofs_per_s_per_gpu": K * per_thread / wall, "all_equal_to_serial_proof": True}
     res = {
         "metric": "groth16_prove_joinsplit_shaped", "curve": args.curve,
         "constraints": cs.num_constraints, "variables": cs.num_variables, "domain": cs.domain_size(),
@@ -74,6 +119,8 @@ def measure(args, ctx=None):
         "timing": "assignment in host memory -> proof in host memory; key resident on device",
         "setup_s": {"circuit": t_circ, "keygen": t_key},
     }
+    if inflight:
+        res["in_flight"] = inflight
     if not args.no_cpu:
         import cpu_oracle
 

@@ -354,7 +354,7 @@ int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out) {
   ZG_HIP(hipSetDevice(ctx->device));
   PkBase* impl = nullptr;
   ZG_TRY(ops->pk_create(ctx, curve, view, &impl));
-  zg_pk* pk = new (std::nothrow) zg_pk{ctx, impl};
+  zg_pk* pk = new (std::nothrow) zg_pk{ctx, impl, false};
   if (!pk) {
     delete impl;
     return ZG_ERR_OUT_OF_MEMORY;
@@ -366,7 +366,30 @@ int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out) {
 void zg_pk_free(zg_pk* pk) {
   if (!pk) return;
   delete pk->impl;
+  if (pk->owns_ctx) zg_ctx_destroy(pk->ctx);
   delete pk;
+}
+
+int zg_pk_clone(zg_pk* pk, zg_pk** out) {
+  if (!pk || !out) return ZG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  ZG_HIP(hipSetDevice(pk->ctx->device));
+  zg_ctx* c = nullptr;
+  ZG_TRY(zg_ctx_create(pk->ctx->device, &c));
+  PkBase* impl = nullptr;
+  int s = pk->impl->clone_onto(c, &impl);
+  if (s != ZG_OK) {
+    zg_ctx_destroy(c);
+    return s;
+  }
+  zg_pk* q = new (std::nothrow) zg_pk{c, impl, true};
+  if (!q) {
+    delete impl;
+    zg_ctx_destroy(c);
+    return ZG_ERR_OUT_OF_MEMORY;
+  }
+  *out = q;
+  return ZG_OK;
 }
 
 int zg_pk_domain_size(const zg_pk* pk, size_t* m) {

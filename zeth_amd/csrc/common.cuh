@@ -147,11 +147,13 @@ struct PkBase {
   virtual int witness_map_out(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
                               int out_form, void* h_out) = 0;
   virtual size_t domain_size() const = 0;
+  virtual int clone_onto(zg_ctx* ctx, PkBase** out) const = 0;
 };
 
 struct zg_pk {
   zg_ctx* ctx;
   PkBase* impl;
+  bool owns_ctx = false;  // clones carry a context of their own
 };
 
 // per-curve scalar-field entry points (fr_inst.hip)

@@ -27,6 +27,8 @@
 namespace zg {
 
 static constexpr int MSM_MAX_C = 16;
+static constexpr uint32_t COMBINE_SERIAL_MAX = 8;  // units folded serially by the first unit's lane; more: tree (k_combine_tree)
+static constexpr uint32_t COMBINE_CHUNK = 512;     // units per workgroup and launch of the tree
 static constexpr int MSM_MAX_W = 48;
 
 struct AddConst {
@@ -163,10 +165,11 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 }
 
 static __global__ void __launch_bounds__(256) k_zero_u32(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b,
-                                                          size_t nb_) {
+                                                          size_t nb_, uint32_t* __restrict__ one_word) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < na) a[i] = 0;
   if (i < nb_) b[i] = 0;
+  if (i == 0) one_word[0] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,12 +205,13 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t nhi /* partitions of 256 buckets (0: single-level sort) */,
                                                 uint32_t* __restrict__ cursor1 /* [W][nhi] */,
                                                 uint32_t* __restrict__ pstart /* [W][nhi + 1] */,
-                                                uint32_t* __restrict__ lencur /* [W][1024]: first slot of each unit length */) {
-  __shared__ uint32_t sa[1024], sb[1024], lh[1025];
+                                                uint32_t* __restrict__ lencur /* [W][1024]: first slot of each unit length */,
+                                                uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */) {
+  __shared__ uint32_t sa[1024], sb[1024], sc[1024], lh[1025];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   const uint32_t per = (nb + 1023) / 1024;
   const uint32_t b0 = tid * per;
-  uint32_t ca = 0, cb = 0;
+  uint32_t ca = 0, cb = 0, cf = 0;
   lh[tid] = 0;
   if (tid == 0) lh[1024] = 0;
   __syncthreads();
@@ -218,6 +222,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
       ca += v;
       cb += (v + L - 1) / L;
       if (v > L) atomicMax(&wunits[gridDim.x], (v + L - 1) / L);
+      cf += v / L;
       // histogram of unit lengths (1..L <= 1024): v / L full units and one of v % L
       if (v >= L) atomicAdd(&lh[L], v / L);
       if (v % L) atomicAdd(&lh[v % L], 1u);
@@ -241,19 +246,22 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
   }
   sa[tid] = ca;
   sb[tid] = cb;
+  sc[tid] = cf;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t xa = 0, xb = 0;
+    uint32_t xa = 0, xb = 0, xc = 0;
     if (tid >= off) {
       xa = sa[tid - off];
       xb = sb[tid - off];
+      xc = sc[tid - off];
     }
     __syncthreads();
     sa[tid] += xa;
     sb[tid] += xb;
+    sc[tid] += xc;
     __syncthreads();
   }
-  uint32_t ea = sa[tid] - ca, eb = sb[tid] - cb;  // exclusive prefixes
+  uint32_t ea = sa[tid] - ca, eb = sb[tid] - cb, ef = sc[tid] - cf;  // exclusive prefixes
   if (tid == 1023) {
     wunits[w] = sb[1023];
     if (nhi) pstart[(size_t)w * (nhi + 1) + nhi] = (uint32_t)((size_t)w * n) + sa[1023];
@@ -271,8 +279,10 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
       }
       boff[(size_t)w * nb + b] = abase + ea;
       ufirst[(size_t)w * nb + b] = ubase + eb;
+      ffirst[(size_t)w * nb + b] = ef;  // full-length units before this bucket: their slots need no atomics
       ea += v;
       eb += (v + L - 1) / L;
+      ef += v / L;
     }
   }
 }
@@ -411,29 +421,53 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
   }
 }
 
-static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
-                                                const uint32_t* __restrict__ ufirst, uint32_t nb, uint32_t W, uint32_t L,
-                                                uint32_t cap, UnitDesc* __restrict__ units, uint32_t* __restrict__ lencur,
-                                                uint32_t* __restrict__ order /* [W][cap]: unit ids, longest first */) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)nb * W) return;
-  const uint32_t w = (uint32_t)(g / nb);
-  uint32_t v = cnt[g];
-  uint32_t u = ufirst[g];
-  uint64_t start = boff[g];
-  // one slot claim for all full-length units of the bucket (a 0/1-heavy witness puts thousands into one bucket)
-  const uint32_t full = v / L, rem = v % L;
+// Unit table and the longest-first order.  k_units: one lane per bucket writes the bucket's first COMBINE_SERIAL_MAX
+// units and lists the bucket as heavy when it has more; k_units_heavy: the remaining units of the heavy buckets,
+// one lane each (a bucket holding half of all entries -- the "1" scalars of a witness -- has thousands).
+// Slots of the order: full-length units are ranked by a scan (no atomics), the one partial unit of a bucket claims its
+// slot in its length class atomically.
+__device__ __forceinline__ void emit_unit(uint32_t k, uint32_t g, uint32_t w, uint32_t v, uint32_t u0, uint32_t start,
+                                          uint32_t full_rank, uint32_t L, uint32_t cap, UnitDesc* __restrict__ units,
+                                          uint32_t* __restrict__ lencur, uint32_t* __restrict__ order) {
+  const uint32_t rest = v - k * L;
+  const uint32_t len = rest < L ? rest : L;
+  units[u0 + k] = UnitDesc{(uint64_t)start + (uint64_t)k * L, len, g};
   uint32_t* slots = order + (size_t)w * cap;
-  if (full) {
-    const uint32_t pos = atomicAdd(&lencur[(size_t)w * 1024 + (L - 1)], full);
-    for (uint32_t k = 0; k < full; k++) {
-      units[u + k] = UnitDesc{start + (uint64_t)k * L, L, (uint32_t)g};
-      slots[pos + k] = u + k;
-    }
-  }
-  if (rem) {
-    units[u + full] = UnitDesc{start + (uint64_t)full * L, rem, (uint32_t)g};
-    slots[atomicAdd(&lencur[(size_t)w * 1024 + (rem - 1)], 1u)] = u + full;
+  if (len == L) slots[lencur[(size_t)w * 1024 + (L - 1)] + full_rank + k] = u0 + k;
+  else slots[atomicAdd(&lencur[(size_t)w * 1024 + (len - 1)], 1u)] = u0 + k;
+}
+
+static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
+                                                const uint32_t* __restrict__ ufirst, const uint32_t* __restrict__ ffirst,
+                                                uint32_t nb, uint32_t W, uint32_t L, uint32_t cap,
+                                                UnitDesc* __restrict__ units, uint32_t* __restrict__ lencur,
+                                                uint32_t* __restrict__ order /* [W][cap]: unit ids, longest first */,
+                                                uint32_t* __restrict__ heavy /* [0] = count, then ids of heavy buckets */) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nb * W) return;
+  const uint32_t v = cnt[g];
+  if (!v) return;
+  const uint32_t w = (uint32_t)(g / nb);
+  const uint32_t nu = (v + L - 1) / L;
+  if (nu > COMBINE_SERIAL_MAX) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)g;
+  const uint32_t u0 = ufirst[g], start = boff[g], fr = ffirst[g];
+  const uint32_t mine = nu < COMBINE_SERIAL_MAX ? nu : COMBINE_SERIAL_MAX;
+  for (uint32_t k = 0; k < mine; k++) emit_unit(k, (uint32_t)g, w, v, u0, start, fr, L, cap, units, lencur, order);
+}
+
+static __global__ void __launch_bounds__(256) k_units_heavy(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
+                                                      const uint32_t* __restrict__ ufirst, const uint32_t* __restrict__ ffirst,
+                                                      uint32_t nb, uint32_t L, uint32_t cap, UnitDesc* __restrict__ units,
+                                                      uint32_t* __restrict__ lencur, uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ heavy) {
+  const uint32_t nheavy = heavy[0];
+  for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
+    const uint32_t g = heavy[1 + hi];
+    const uint32_t v = cnt[g], w = g / nb;
+    const uint32_t nu = (v + L - 1) / L;
+    const uint32_t u0 = ufirst[g], start = boff[g], fr = ffirst[g];
+    for (uint32_t k = COMBINE_SERIAL_MAX + blockIdx.x * blockDim.x + threadIdx.x; k < nu; k += gridDim.x * blockDim.x)
+      emit_unit(k, g, w, v, u0, start, fr, L, cap, units, lencur, order);
   }
 }
 
@@ -518,26 +552,58 @@ __global__ void __launch_bounds__(256, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDes
   part[u] = acc;
 }
 
-// Buckets that were split into several units (skewed scalars: 0/1-heavy witnesses, short top windows) are
-// folded by a pairwise tree, one launch per level: part[u0 + i] += part[u0 + i + s] for i % 2s == 0.
+// Buckets that were split into several units (skewed scalars: 0/1-heavy witnesses, short top windows) are folded into
+// their first unit.  Up to COMBINE_SERIAL_MAX units: the first unit's lane adds the others one after another
+// (k_combine_light).  More ("heavy" buckets, listed by k_units -- a JoinSplit witness has one, holding half of all
+// entries in thousands of units): a tree with the active lanes compacted onto the first waves of a 256-lane workgroup,
+// 512 units per workgroup and launch (k_combine_tree with stride 1, then stride 512 over the chunk heads).
 template <class F>
-__global__ void __launch_bounds__(1024) k_combine(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
-                                                  uint32_t W, uint32_t cap, const uint32_t* __restrict__ cnt,
-                                                  const uint32_t* __restrict__ ufirst, uint32_t L, uint32_t s,
-                                                  XYZZ<F>* __restrict__ part) {
-  if (s >= wunits[W]) return;  // no bucket has more than s units
+__global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
+                                                        uint32_t W, uint32_t cap, const uint32_t* __restrict__ cnt,
+                                                        const uint32_t* __restrict__ ufirst, uint32_t L,
+                                                        XYZZ<F>* __restrict__ part) {
+  if (wunits[W] <= 1) return;  // no bucket has more than one unit
   const uint32_t w = blockIdx.y;
   const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
   if (ul >= wunits[w]) return;
   const uint32_t u = w * cap + ul;
   const uint32_t b = units[u].bucket;
-  const uint32_t i = u - ufirst[b];
+  if (ufirst[b] != u) return;  // only a bucket's first unit
   const uint32_t nu = (cnt[b] + L - 1) / L;
-  if ((i & (2 * s - 1)) == 0 && i + s < nu) {
-    XYZZ<F> a = part[u];
-    XYZZ<F> c = part[u + s];
+  if (nu < 2 || nu > COMBINE_SERIAL_MAX) return;
+  XYZZ<F> a = part[u];
+  for (uint32_t k = 1; k < nu; k++) {
+    XYZZ<F> c = part[u + k];
     xyzz_add(a, c);
-    part[u] = a;
+  }
+  part[u] = a;
+}
+
+// grid (chunk slots, heavy slots); elements of this level: part[first + stride * j], j < ceil(units / stride)
+template <class F>
+__global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
+                                                       const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
+                                                       uint32_t L, uint32_t stride, XYZZ<F>* __restrict__ part) {
+  const uint32_t nheavy = heavy[0];
+  for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
+    const uint32_t g = heavy[1 + hi];
+    const uint32_t nu = (cnt[g] + L - 1) / L;
+    const uint32_t nelem = (nu + stride - 1) / stride;
+    if (nelem < 2) continue;
+    XYZZ<F>* base = part + ufirst[g];
+    for (uint32_t c0 = blockIdx.x * COMBINE_CHUNK; c0 < nelem; c0 += gridDim.x * COMBINE_CHUNK) {
+      const uint32_t c1 = c0 + COMBINE_CHUNK < nelem ? c0 + COMBINE_CHUNK : nelem;
+      for (uint32_t s = 1; s < COMBINE_CHUNK && c0 + s < c1; s <<= 1) {
+        const uint32_t j0 = c0 + 2 * s * threadIdx.x;
+        if (j0 + s < c1) {
+          XYZZ<F> a = base[(size_t)stride * j0];
+          XYZZ<F> c = base[(size_t)stride * (j0 + s)];
+          xyzz_add(a, c);
+          base[(size_t)stride * j0] = a;
+        }
+        __syncthreads();
+      }
+    }
   }
 }
 

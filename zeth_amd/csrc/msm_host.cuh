@@ -171,7 +171,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
   const uint32_t nhi = p.nb >= 512 ? (p.nb >> 8) : 0;  // two-level sort when a window has >= 512 buckets
   size_t need = (nhi ? zg_ctx::ws_round(WN * 4) + zg_ctx::ws_round(WN) + 2 * zg_ctx::ws_round((size_t)p.W * (nhi + 1) * 4) : 0) +
-                zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 4 * zg_ctx::ws_round(WB * 4) +
+                zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 5 * zg_ctx::ws_round(WB * 4) + zg_ctx::ws_round((WB + 1) * 4) +
                 zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) + zg_ctx::ws_round(WC * 4) +
                 zg_ctx::ws_round((size_t)p.W * 1024 * 4) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
@@ -182,6 +182,8 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   uint32_t* cursor = ctx->ws_take<uint32_t>(WB);
   uint32_t* boff = ctx->ws_take<uint32_t>(WB);
   uint32_t* ufirst = ctx->ws_take<uint32_t>(WB);
+  uint32_t* ffirst = ctx->ws_take<uint32_t>(WB);
+  uint32_t* heavy = ctx->ws_take<uint32_t>(WB + 1);
   uint32_t* wunits = ctx->ws_take<uint32_t>(p.W + 1 + 64);  // [W] unit totals, [W] max units per bucket, then 64 dense-scalar counters
   UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
   uint32_t* order = ctx->ws_take<uint32_t>(WC);
@@ -197,7 +199,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     pstart = ctx->ws_take<uint32_t>((size_t)p.W * (nhi + 1));
     if (!mid_ent || !mid_lo || !cursor1 || !pstart) return ZG_ERR_OUT_OF_MEMORY;
   }
-  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !wunits || !units || !order || !lencur || !part || !seg)
+  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !ffirst || !heavy || !wunits || !units || !order || !lencur || !part || !seg)
     return ZG_ERR_OUT_OF_MEMORY;
 
   hipStream_t st = ctx->stream;
@@ -211,14 +213,14 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->prof_begin();
   ctx->mark("digits");
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
-                     (size_t)(p.W + 1 + 64));
+                     (size_t)(p.W + 1 + 64), heavy);
   hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
                      p.c, p.W, p.K, dig, ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr);
   ctx->mark("hist");
   hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
   ctx->mark("scan");
   hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits, nhi,
-                     cursor1, pstart, lencur);
+                     cursor1, pstart, lencur, ffirst);
   ctx->mark("scatter");
   if (nhi) {
     hipLaunchKernelGGL(k_scatter_hi, dim3((unsigned)((n + SORT_TILE1 - 1) / SORT_TILE1), p.W), dim3(1024), 0, st, dig, n,
@@ -232,15 +234,25 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     hipLaunchKernelGGL(k_scatter, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cursor, sorted);
   }
   ctx->mark("units");
-  hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, p.nb,
-                     (uint32_t)p.W, p.L, p.cap, units, lencur, order);
+  hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb,
+                     (uint32_t)p.W, p.L, p.cap, units, lencur, order, heavy);
+  hipLaunchKernelGGL(k_units_heavy, dim3(32, 16), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb, p.L, p.cap, units, lencur,
+                     order, heavy);
   ctx->mark("accum");
   hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, p.cap, order, sorted,
                      d_bases, part, zg_debug_base_mask());
   ctx->mark("combine");
-  for (uint32_t s = 1; s < (uint32_t)((n + p.L - 1) / p.L); s <<= 1)
-    hipLaunchKernelGGL((k_combine<F>), dim3((p.cap + 1023) / 1024, p.W), dim3(1024), 0, st, units, wunits, (uint32_t)p.W,
-                       p.cap, cnt, ufirst, p.L, s, part);
+  hipLaunchKernelGGL((k_combine_light<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
+                     p.cap, cnt, ufirst, p.L, part);
+  {
+    uint32_t chunks = (p.cap + COMBINE_CHUNK - 1) / COMBINE_CHUNK;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
+    if (n / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK)  // more than 2^18 units in one bucket: a third level
+      hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L,
+                         COMBINE_CHUNK * COMBINE_CHUNK, part);
+  }
   ctx->mark("reduce1");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
                      p.k, p.L, (uint32_t)p.W, seg);

@@ -107,6 +107,7 @@ struct ProvingKeyDev : PkBase {
   zg_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t dense_hint[4] = {0, 0, 0, 0};
   hipEvent_t w_ready = nullptr;
+  bool owns_key = true;  // false for a clone: bases and matrices belong to the key it was cloned from
 
   ~ProvingKeyDev() override {
     hipSetDevice(ctx->device);
@@ -114,12 +115,14 @@ struct ProvingKeyDev : PkBase {
     for (auto& l : lane)
       if (l) zg_ctx_destroy(l);
     if (w_ready) hipEventDestroy(w_ready);
-    for (auto& M : mat) {
-      hipFree(M.row_ptr);
-      hipFree(M.col);
-      hipFree(M.val);
+    if (owns_key) {
+      for (auto& M : mat) {
+        hipFree(M.row_ptr);
+        hipFree(M.col);
+        hipFree(M.val);
+      }
+      hipFree(A); hipFree(B1); hipFree(B2); hipFree(H); hipFree(L); hipFree(B_idx);
     }
-    hipFree(A); hipFree(B1); hipFree(B2); hipFree(H); hipFree(L); hipFree(B_idx);
     hipFree(w); hipFree(ev[0]); hipFree(ev[1]); hipFree(ev[2]); hipFree(tmp); hipFree(bsc); hipFree(assign);
   }
 
@@ -201,6 +204,14 @@ struct ProvingKeyDev : PkBase {
       host_affine_convert(&beta_g2, 1, 1);
       host_affine_convert(&delta_g2, 1, 1);
     }
+    ZG_TRY(alloc_scratch());
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));
+    return ZG_OK;
+  }
+
+  // side streams and per-proof device scratch (everything a proof in flight writes)
+  int alloc_scratch() {
     for (auto& l : lane) {
       ZG_TRY(zg_ctx_create_prio(ctx->device, +1, &l));
       l->want_dense = true;
@@ -217,8 +228,27 @@ struct ProvingKeyDev : PkBase {
     z_inv = Fr::inv(Fr::sub(host_pow_u64(g, m), Fr::one()));
     NttDomain<Fr>* D = nullptr;
     ZG_TRY(ntt_get_domain<Fr>(ctx, curve, log_m, &D));
-    ZG_HIP(hipGetLastError());
-    ZG_HIP(hipStreamSynchronize(st));
+    return ZG_OK;
+  }
+
+  // a second prover over the same resident key: shares bases and matrices, owns its scratch and streams
+  int clone_onto(zg_ctx* c, PkBase** out) const override {
+    auto* p = new ProvingKeyDev<Fq, Fq2T, Fr>();
+    p->owns_key = false;
+    p->ctx = c;
+    p->curve = curve;
+    p->num_inputs = num_inputs; p->num_vars = num_vars; p->nc = nc; p->m = m; p->log_m = log_m;
+    for (int k = 0; k < 3; k++) p->mat[k] = mat[k];
+    p->alpha_g1 = alpha_g1; p->beta_g1 = beta_g1; p->delta_g1 = delta_g1; p->beta_g2 = beta_g2; p->delta_g2 = delta_g2;
+    p->A = A; p->B1 = B1; p->H = H; p->L = L; p->B2 = B2; p->B_idx = B_idx;
+    p->A_len = A_len; p->B_len = B_len; p->H_len = H_len; p->L_len = L_len;
+    int s = p->alloc_scratch();
+    if (s == ZG_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = ZG_ERR_HIP;
+    if (s != ZG_OK) {
+      delete p;
+      return s;
+    }
+    *out = p;
     return ZG_OK;
   }
 
@@ -285,8 +315,10 @@ struct ProvingKeyDev : PkBase {
     // the longest dependent chain (constraint evaluation, seven transforms, H evaluation) goes first, on the
     // high-priority main stream; the side lanes have the lowest stream priority
     ZG_TRY(qap_h());
-    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, 0));
-    auto width = [](uint32_t dense) { return dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
+    static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
+    static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
+    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c));
+    auto width = [](uint32_t dense) { return lane_c ? lane_c : dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
     ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0])));
     ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1])));
     ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2])));

@@ -149,6 +149,15 @@ template<typename ppT, typename GroupT> int cmd_lagrange(char **argv)
         l_factors[j] = Fr<ppT>::one();
         out.push_back(eval.evaluate_from_lagrange_factors(l_factors));
     }
+    // the comparison the reference test makes: against the Lagrange evaluations from the group-element FFT
+    std::vector<GroupT> lagrange = powers;
+    compute_lagrange_from_powers<ppT, GroupT>(lagrange);
+    for (size_t j = 0; j < domain.m; ++j) {
+        if (out[j] != lagrange[j]) {
+            std::cerr << "L_" << j << ": evaluator_from_lagrange and compute_lagrange_from_powers disagree\n";
+            return 1;
+        }
+    }
     std::ofstream out_s = open_binary_output_file(argv[5]);
     group_elements_write_bytes(out, out_s);
     return 0;

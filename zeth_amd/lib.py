@@ -81,6 +81,7 @@ def load_library():
     L.zg_ntt.argtypes = [vp, ci, vp, ctypes.c_uint, ci, ci, ci, ci]
     L.zg_pk_create.argtypes = [vp, ci, ctypes.POINTER(PkView), ctypes.POINTER(vp)]
     L.zg_pk_free.argtypes = [vp]
+    L.zg_pk_clone.argtypes = [vp, ctypes.POINTER(vp)]
     L.zg_pk_free.restype = None
     L.zg_pk_domain_size.argtypes = [vp, ctypes.POINTER(sz)]
     L.zg_prove.argtypes = [vp, vp, sz, vp, sz, ci, vp, vp, ci, vp]
@@ -389,6 +390,12 @@ class ProvingKey:
         h = ctypes.c_void_p()
         _check(ctx._L.zg_pk_create(ctx._h, curve, ctypes.byref(view), ctypes.byref(h)))
         return cls(ctx, curve, h, None)
+
+    def clone(self) -> "ProvingKey":
+        """A second prover over the same resident key for another thread (zg_pk_clone); free it before `self`."""
+        h = ctypes.c_void_p()
+        _check(self.ctx._L.zg_pk_clone(self._h, ctypes.byref(h)))
+        return ProvingKey(self.ctx, self.curve, h, self)
 
     def free(self):
         if self._h:
