@@ -191,6 +191,15 @@ def main():
         achieved = n_local * MAC_PER_POINT_BN254_G1 / (k_ms * 1e-3)
         # algorithmic HBM bytes of the accumulation kernel: per (point, window) one 64 B base + one 4 B sorted entry
         hbm_bytes = n_local * 16 * 68
+        # HBM bytes per k_accum launch from the PMC passes of this same workload (the counters cannot be read from
+        # inside this process); only quoted for the size they were collected at
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))["kernels"]["k_accum"]
+            if n_local == 1 << 24:
+                traffic = pmc["FETCH_SIZE_bytes_per_launch"] + pmc["WRITE_SIZE_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "bn254_g1_msm_2^%d_throughput" % args.log_n,
             "value": n_total / (elapsed / args.steps),
@@ -218,7 +227,9 @@ def main():
                 "unit": "TMAC/s",
                 "frac": achieved / PEAK_MAC_PER_S,
                 "kernel_ms": k_ms,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per k_accum launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; profiles/r1_pmc_hbm_traffic.json)",
+                "algorithmic_bytes": hbm_bytes,
                 "hbm_algorithmic_GBps": hbm_bytes / (k_ms * 1e-3) / 1e9,
                 "hbm_frac": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "MSM is integer-multiply bound (SURVEY 8d): achieved = 21760 MAC/point x points / kernel time; peak = "
