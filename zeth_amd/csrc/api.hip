@@ -72,6 +72,12 @@ void zg_ctx_destroy(zg_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->side_stream) {
+    hipStreamSynchronize(c->side_stream);
+    hipStreamDestroy(c->side_stream);
+    hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_join);
+  }
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   for (auto& kv : c->ntt_domains) delete kv.second;
   if (c->ws) hipFree(c->ws);

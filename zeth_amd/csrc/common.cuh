@@ -33,6 +33,16 @@ struct zg_ctx {
   std::map<uint32_t, NttDomainBase*> ntt_domains;  // key = curve << 8 | log m
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream + events of the MSM's window-group pipeline (created on first use)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_init() {
+    if (side_stream) return ZG_OK;
+    ZG_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    ZG_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    return ZG_OK;
+  }
   // grow-only workspace, bump-allocated per call
   char* ws = nullptr;
   size_t ws_cap = 0, ws_used = 0;

@@ -329,11 +329,11 @@ static constexpr uint32_t SORT_TILE2 = 8192;
 // image out linearly, so that a wave writes 64 consecutive entries of (mostly) one run: full-line global stores.
 static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __restrict__ dig, size_t n, uint32_t nhi,
                                                       uint32_t* __restrict__ cursor1, uint32_t* __restrict__ mid_ent,
-                                                      uint8_t* __restrict__ mid_lo) {
+                                                      uint8_t* __restrict__ mid_lo, uint32_t w0 /* first window of the group */) {
   __shared__ uint32_t h[128], lstart[128], gbase[128];
   __shared__ uint32_t buf_ent[SORT_TILE1];
   __shared__ uint8_t buf_lo[SORT_TILE1], buf_bin[SORT_TILE1];
-  const uint32_t w = blockIdx.y;
+  const uint32_t w = w0 + blockIdx.y;
   const size_t lo = (size_t)blockIdx.x * SORT_TILE1;
   size_t hi = lo + SORT_TILE1;
   if (hi > n) hi = n;
@@ -380,11 +380,12 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
 static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __restrict__ mid_ent,
                                                      const uint8_t* __restrict__ mid_lo,
                                                      const uint32_t* __restrict__ pstart, uint32_t nhi, uint32_t nb,
-                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
+                                                     uint32_t w0 /* first window of the group */) {
   __shared__ uint32_t h[256], lstart[256], gbase[256];
   __shared__ uint32_t buf_ent[SORT_TILE2];
   __shared__ uint8_t buf_bin[SORT_TILE2];
-  const uint32_t p = blockIdx.y, w = blockIdx.z;
+  const uint32_t p = blockIdx.y, w = w0 + blockIdx.z;
   const uint32_t start = pstart[(size_t)w * (nhi + 1) + p], end = pstart[(size_t)w * (nhi + 1) + p + 1];
   uint32_t* cur = cursor + (size_t)w * nb + (size_t)p * 256;
   for (uint32_t lo = start + blockIdx.x * SORT_TILE2; lo < end; lo += gridDim.x * SORT_TILE2) {
@@ -516,15 +517,19 @@ __device__ __forceinline__ void xyzz_madd_wave(XYZZ<F>& acc, const Affine<F>& p)
 #ifndef ZG_ACCUM_MIN_WAVES
 #define ZG_ACCUM_MIN_WAVES 1
 #endif
+#ifndef ZG_ACCUM_BLOCK
+#define ZG_ACCUM_BLOCK 256
+#endif
 template <class F>
-__global__ void __launch_bounds__(256, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
+__global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
                                                 uint32_t cap, const uint32_t* __restrict__ order,
                                                 const uint32_t* __restrict__ sorted,
                                                 const Affine<F>* __restrict__ bases, XYZZ<F>* __restrict__ part,
-                                                const uint32_t idx_mask /* 0x7FFFFFFF: strips the sign bit */) {
+                                                const uint32_t idx_mask /* 0x7FFFFFFF: strips the sign bit */,
+                                                const uint32_t w_end /* windows [w_end - gridDim.y, w_end) */) {
   // Workgroups are dispatched in blockIdx order.  The top window comes first: its digits cover fewer values (the scalar's
   // leading bits), so its buckets -- and units -- are the longest, and a long unit that starts late is the kernel's tail.
-  const uint32_t w = gridDim.y - 1 - blockIdx.y;
+  const uint32_t w = w_end - 1 - blockIdx.y;
   const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
   if (ul >= wunits[w]) return;
   const size_t u = order[(size_t)w * cap + ul];  // longest units first; the lanes of a wave get (nearly) equal lengths
