@@ -100,7 +100,13 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   if (maxchunk < 1) maxchunk = 1;
   if (nchunk > maxchunk) nchunk = maxchunk;
   p.nchunk = nchunk;
-  p.T = p.nb < 1024 ? p.nb : 1024;
+  // bucket segments per window: a reduce1 lane runs 2k dependent additions plus a c-bit double-and-add (~7 us each),
+  // reduce2 then folds the T segment sums of a window; measured best: 1024 segments up to 2^14 buckets, 2048 above
+  p.T = p.nb < 1024 ? p.nb : (p.nb >= 32768 ? 2048 : 1024);
+  if (const char* e = getenv("ZG_MSM_SEGMENTS")) {  // tuning knob (power of two)
+    uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
+    if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) p.T = v;
+  }
   p.k = p.nb / p.T;
   for (int i = 0; i < 9; i++) p.K.k[i] = 0;
   for (int w = 0; w < p.W; w++) {
