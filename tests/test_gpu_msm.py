@@ -144,3 +144,43 @@ def test_msm_skewed_scalars_two_level_sort(ctx, window_bits):
     k = sum(a * (t0 + i * d) for i, a in enumerate(same)) % C.r
     assert bases.msm(same, window_bits=window_bits) == C.G1.mul(k, C.G1.gen)
     bases.free()
+
+
+def test_msm_degenerate_scalar_sets_at_size(ctx):
+    """SURVEY 8d edge-case sets at 2^20 points, checked by the closed form: all ones (one bucket holds every entry:
+    thousands of units, both levels of the combine tree), all r - 1, all zero, one constant in every window, and a
+    JoinSplit-like mix (90 % bits).  Scalars are uploaded as bytes; the closed form uses sums of arithmetic series."""
+    import numpy as np
+
+    import zeth_amd
+
+    C = BN254
+    r = C.r
+    n = 1 << 20
+    t0, d = 0x1F2E3D4C5B6A79, 0x1122334455667
+    bases = zeth_amd.Bases.generate(ctx, 0, 1, n, t0, d)
+    s1 = (n * t0 + d * (n * (n - 1) // 2)) % r  # sum_i (t0 + i d)
+
+    def run(words):
+        return bases.msm(words.astype("<u8").tobytes())
+
+    def const(v):
+        w = np.zeros((n, 4), dtype=np.uint64)
+        for k in range(4):
+            w[:, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        return w
+
+    assert run(const(1)) == C.G1.mul(s1, C.G1.gen)
+    assert run(const(r - 1)) == C.G1.mul((r - s1) % r, C.G1.gen)
+    assert run(const(0)) is None
+    k = 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % r
+    assert run(const(k)) == C.G1.mul(k * s1 % r, C.G1.gen)
+    # 90 % bits, 10 % small values: sum over the selected indices
+    rng = np.random.default_rng(5)
+    vals = np.where(rng.random(n) < 0.9, rng.integers(0, 2, n), rng.integers(2, 1 << 16, n)).astype(np.uint64)
+    w = np.zeros((n, 4), dtype=np.uint64)
+    w[:, 0] = vals
+    idx = np.arange(n, dtype=object)
+    total = (int(vals.astype(object).sum()) * t0 + d * int((vals.astype(object) * idx).sum())) % r
+    assert run(w) == C.G1.mul(total, C.G1.gen)
+    bases.free()

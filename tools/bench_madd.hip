@@ -3,7 +3,10 @@
 // case with cycles per wave-level operation (at the shader clock measured alongside with clock64/wall_clock64).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I zeth_amd/csrc tools/bench_madd.hip -o build/bench_madd
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
+
+#include <algorithm>
 
 #include "msm.cuh"
 
@@ -119,15 +122,29 @@ static void run(const char* name, K kern, int blocks, int iters, double ops_per_
 }
 
 // k_accum itself on fabricated inputs: every unit `len` entries long, entries uniformly random over `nbases` points
-static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbases, const Affine<F>* dp8) {
+// mode 0: every unit `len` long.  mode 1: lengths len +- sqrt(len) (Gaussian, like bucket loads), in arrival order.
+// mode 2: the same lengths handed out longest first (what k_units' order does).
+static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbases, const Affine<F>* dp8, int mode = 0, int extra_blocks = 0) {
   const size_t lanes = (size_t)blocks * 256;
   std::vector<UnitDesc> hu(lanes);
-  std::vector<uint32_t> hord(lanes), hsorted(lanes * len), hw(2);
+  std::vector<uint32_t> hord(lanes), hw(2);
   uint64_t x = 88172645463325252ull;
+  auto rnd = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  uint64_t total = 0;
   for (size_t i = 0; i < lanes; i++) {
-    hu[i] = UnitDesc{(uint64_t)i * len, len, (uint32_t)i};
+    uint32_t l = len;
+    if (mode) {
+      double g = 0;
+      for (int k = 0; k < 12; k++) g += (double)(rnd() & 0xFFFFFF) / 16777216.0;
+      l = (uint32_t)((double)len + (g - 6.0) * sqrt((double)len));
+      if (l < 1) l = 1;
+    }
+    hu[i] = UnitDesc{total, l, (uint32_t)i};
+    total += l;
     hord[i] = (uint32_t)i;
   }
+  if (mode == 2) std::sort(hord.begin(), hord.end(), [&](uint32_t a, uint32_t b) { return hu[a].len > hu[b].len; });
+  std::vector<uint32_t> hsorted(total);
   for (auto& e : hsorted) {
     x ^= x << 13; x ^= x >> 7; x ^= x << 17;
     e = (uint32_t)(x % nbases) | ((x >> 40) & 1 ? 0x80000000u : 0u);
@@ -159,15 +176,15 @@ static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbase
   float best = 1e9f;
   for (int r = 0; r < 3; r++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_accum<F>), dim3(blocks, 1), dim3(256), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu);
+    hipLaunchKernelGGL((k_accum<F>), dim3(blocks + extra_blocks, 1), dim3(256), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu, 1u);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
-  double wave_ops = (double)blocks * 4 * len;
-  printf("{\"case\": \"%s\", \"blocks\": %d, \"len\": %u, \"nbases\": %u, \"ms\": %.3f, \"simd_cycles_per_wave_op_at_2.4GHz\": %.0f}\n",
-         name, blocks, len, nbases, best, best * 1e-3 * 2.4e9 * 1024.0 / wave_ops);
+  double wave_ops = (double)total / 64.0;
+  printf("{\"case\": \"%s\", \"mode\": %d, \"blocks\": %d, \"len\": %u, \"nbases\": %u, \"ms\": %.3f, \"simd_cycles_per_wave_op_at_2.4GHz\": %.0f}\n",
+         name, mode, blocks, len, nbases, best, best * 1e-3 * 2.4e9 * 1024.0 / wave_ops);
   hipFree(du); hipFree(dord); hipFree(dsorted); hipFree(dw); hipFree(db); hipFree(dpart);
 }
 
@@ -212,6 +229,12 @@ int main() {
   run_accum("k_accum_synth", 512, 512, 1u << 12, dp);
   run_accum("k_accum_synth", 2048, 512, 1u << 12, dp);
   run_accum("k_accum_synth", 2048, 512, 1u << 22, dp);
+  run_accum("k_accum_synth", 2048, 512, 1u << 22, dp, 1);
+  run_accum("k_accum_synth", 2048, 512, 1u << 22, dp, 2);
+  run_accum("k_accum_synth", 2048, 512, 1u << 24, dp, 2);
+  run_accum("k_accum_synth_1040_empty_blocks", 2048, 512, 1u << 22, dp, 2, 1040);
+  run_accum("k_accum_synth", 2048, 64, 1u << 21, dp, 1);
+  run_accum("k_accum_synth", 2048, 64, 1u << 21, dp, 2);
   for (int wps : {1, 3}) run("sub", k_lin<0>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("add", k_lin<1>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("cneg", k_lin<2>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);

@@ -328,6 +328,17 @@ static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restri
 // straight into 2^15 bucket streams writes 4-byte entries to 2^15 different cache lines per block (measured 6.7 ms
 // at 2^24 points); here level 1 splits a tile over <= 128 partitions of 256 buckets (runs of ~128 entries) and level 2
 // finishes each partition on its low 8 bits (runs of ~32 entries), so both levels write in long contiguous runs.
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(x, d);
+    if (lane >= d) x += t;
+  }
+  return x;
+}
+
 static constexpr uint32_t SORT_TILE1 = 8192;
 static constexpr uint32_t SORT_TILE2 = 8192;
 
@@ -351,17 +362,24 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
     if (v != 0) atomicAdd(&h[(uint32_t)((v < 0 ? -v : v) - 1) >> 8], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < 128) {
-    // exclusive scan over <= 128 bins by the first two waves (serial per lane is fine at this size)
-    uint32_t v = threadIdx.x < nhi ? h[threadIdx.x] : 0;
-    uint32_t acc = 0;
-    for (uint32_t k = 0; k < threadIdx.x; k++) acc += (k < nhi ? h[k] : 0);
-    lstart[threadIdx.x] = acc;
-    gbase[threadIdx.x] = v ? atomicAdd(&cursor1[(size_t)w * nhi + threadIdx.x], v) : 0;
+  {
+    // exclusive scan over <= 128 bins: wave prefix sums by the first two waves, then the first wave's total
+    __shared__ uint32_t wsum;
+    uint32_t v = 0, incl = 0;
+    if (threadIdx.x < 128) {
+      v = threadIdx.x < nhi ? h[threadIdx.x] : 0;
+      incl = wave_inclusive_scan(v);
+      if (threadIdx.x == 63) wsum = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
+      lstart[threadIdx.x] = excl;
+      gbase[threadIdx.x] = v ? atomicAdd(&cursor1[(size_t)w * nhi + threadIdx.x], v) : 0;
+      h[threadIdx.x] = excl;  // running local cursors
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (threadIdx.x < 128) h[threadIdx.x] = lstart[threadIdx.x];  // running local cursors
-  __syncthreads();
   for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int v = d[i];
     if (v != 0) {
@@ -388,7 +406,7 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
                                                      const uint32_t* __restrict__ pstart, uint32_t nhi, uint32_t nb,
                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
                                                      uint32_t w0 /* first window of the group */) {
-  __shared__ uint32_t h[256], lstart[256], gbase[256];
+  __shared__ uint32_t h[256], lstart[256], gbase[256], wsum[4];
   __shared__ uint32_t buf_ent[SORT_TILE2];
   __shared__ uint8_t buf_bin[SORT_TILE2];
   const uint32_t p = blockIdx.y, w = w0 + blockIdx.z;
@@ -401,17 +419,25 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[mid_lo[i]], 1u);
     __syncthreads();
-    if (threadIdx.x < 256) {
-      // exclusive scan of 256 counts, serial per lane (256 LDS reads at most; no barriers inside the branch)
-      uint32_t v = h[threadIdx.x];
-      uint32_t excl = 0;
-      for (uint32_t k = 0; k < threadIdx.x; k++) excl += h[k];
-      lstart[threadIdx.x] = excl;
-      gbase[threadIdx.x] = v ? atomicAdd(&cur[threadIdx.x], v) : 0;
+    {
+      // exclusive scan of the 256 counts: wave prefix sums by the first four waves, then the waves' totals
+      uint32_t v = 0, incl = 0;
+      if (threadIdx.x < 256) {
+        v = h[threadIdx.x];
+        incl = wave_inclusive_scan(v);
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
+      }
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        uint32_t off = 0;
+        for (uint32_t q = 0; q < (threadIdx.x >> 6); q++) off += wsum[q];
+        const uint32_t excl = off + incl - v;
+        lstart[threadIdx.x] = excl;
+        gbase[threadIdx.x] = v ? atomicAdd(&cur[threadIdx.x], v) : 0;
+        h[threadIdx.x] = excl;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < 256) h[threadIdx.x] = lstart[threadIdx.x];
-    __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
       uint32_t bin = mid_lo[i];
       uint32_t pos = atomicAdd(&h[bin], 1u);
