@@ -47,9 +47,11 @@ ZG_HD XYZZ<F> xyzz_mdbl(const Affine<F>& p) {
   return r;
 }
 
-// 2 * a  (EFD dbl-2008-s-1, a = 0)
+// 2 * a  (EFD dbl-2008-s-1, a = 0).  The _inl forms are inlined into the latency-bound reduction kernels, where a
+// call (arguments through scratch memory) about doubles the time of each step of a dependent chain; everywhere
+// else the out-of-line forms keep the code small.
 template <class F>
-ZG_HD_COLD XYZZ<F> xyzz_dbl(const XYZZ<F>& a) {
+ZG_HD XYZZ<F> xyzz_dbl_inl(const XYZZ<F>& a) {
   if (a.is_inf()) return a;
   F U = F::dbl(a.y);
   F V = F::sqr(U);
@@ -62,6 +64,10 @@ ZG_HD_COLD XYZZ<F> xyzz_dbl(const XYZZ<F>& a) {
   r.zz = F::mul(V, a.zz);
   r.zzz = F::mul(W, a.zzz);
   return r;
+}
+template <class F>
+ZG_HD_COLD XYZZ<F> xyzz_dbl(const XYZZ<F>& a) {
+  return xyzz_dbl_inl(a);
 }
 
 // acc += affine p  (EFD madd-2008-s; 8M + 2S), all exceptional cases handled
@@ -97,7 +103,9 @@ ZG_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& p) {
 
 // acc += b  (EFD add-2008-s; 12M + 2S)
 template <class F>
-ZG_HD_COLD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
+ZG_HD_COLD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b);
+template <class F>
+ZG_HD void xyzz_add_inl(XYZZ<F>& acc, const XYZZ<F>& b) {
   if (b.is_inf()) return;
   if (acc.is_inf()) {
     acc = b;
@@ -111,7 +119,7 @@ ZG_HD_COLD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
   F R = F::sub(S2, S1);
   if (Pd.is_zero()) {
     if (R.is_zero()) {
-      acc = xyzz_dbl(acc);
+      acc = xyzz_dbl(acc);  // out of line: rare
     } else {
       acc = XYZZ<F>::inf();
     }
@@ -126,6 +134,10 @@ ZG_HD_COLD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
   acc.y = Y3;
   acc.zz = F::mul(F::mul(acc.zz, b.zz), PP);
   acc.zzz = F::mul(F::mul(acc.zzz, b.zzz), PPP);
+}
+template <class F>
+ZG_HD_COLD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
+  xyzz_add_inl(acc, b);
 }
 
 template <class F>

@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict
         if (j0 + s < c1) {
           XYZZ<F> a = base[(size_t)stride * j0];
           XYZZ<F> c = base[(size_t)stride * (j0 + s)];
-          xyzz_add(a, c);
+          xyzz_add_inl(a, c);
           base[(size_t)stride * j0] = a;
         }
         __syncthreads();
@@ -658,18 +658,18 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
   XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
   for (int bb = (int)k - 1; bb >= 0; bb--) {
     size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
-    if (cnt[gid]) xyzz_add(run, part[ufirst[gid]]);  // k_combine left the bucket sum in its first unit
-    xyzz_add(tot, run);
+    if (cnt[gid]) xyzz_add_inl(run, part[ufirst[gid]]);  // k_combine left the bucket sum in its first unit
+    xyzz_add_inl(tot, run);
   }
   // tot = sum (b - j*k + 1) B_b ; add (j*k) * run
   uint32_t start = j * k;
   if (start != 0 && !run.is_inf()) {
     XYZZ<F> r = XYZZ<F>::inf();
     for (int b = 15; b >= 0; b--) {
-      r = xyzz_dbl(r);
-      if ((start >> b) & 1u) xyzz_add(r, run);
+      r = xyzz_dbl_inl(r);
+      if ((start >> b) & 1u) xyzz_add_inl(r, run);
     }
-    xyzz_add(tot, r);
+    xyzz_add_inl(tot, r);
   }
   seg[g] = tot;
 }
@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(1024) k_reduce2(XYZZ<F>* __restrict__ seg, uin
   XYZZ<F>* s = seg + (size_t)blockIdx.x * T;
   if (T > blockDim.x) {  // fold the tail onto the first blockDim entries
     XYZZ<F> a = s[threadIdx.x];
-    for (uint32_t j = threadIdx.x + blockDim.x; j < T; j += blockDim.x) xyzz_add(a, s[j]);
+    for (uint32_t j = threadIdx.x + blockDim.x; j < T; j += blockDim.x) xyzz_add_inl(a, s[j]);
     s[threadIdx.x] = a;
     __syncthreads();
     T = blockDim.x;
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(1024) k_reduce2(XYZZ<F>* __restrict__ seg, uin
     if (threadIdx.x < h) {
       XYZZ<F> a = s[threadIdx.x];
       XYZZ<F> b = s[threadIdx.x + h];
-      xyzz_add(a, b);
+      xyzz_add_inl(a, b);
       s[threadIdx.x] = a;
     }
     __syncthreads();

@@ -256,7 +256,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->mark("units");
   hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb,
                      (uint32_t)p.W, p.L, p.cap, units, lencur, order, heavy);
-  hipLaunchKernelGGL(k_units_heavy, dim3(32, 16), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb, p.L, p.cap, units, lencur,
+  hipLaunchKernelGGL(k_units_heavy, dim3(8, 128), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb, p.L, p.cap, units, lencur,
                      order, heavy);
   ctx->mark("accum");
   const dim3 ablk(ZG_ACCUM_BLOCK);
@@ -273,8 +273,8 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   {
     uint32_t chunks = (p.cap + COMBINE_CHUNK - 1) / COMBINE_CHUNK;
     if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 128), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 128), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
     if (n / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK)  // more than 2^18 units in one bucket: a third level
       hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L,
                          COMBINE_CHUNK * COMBINE_CHUNK, part);
