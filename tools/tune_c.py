@@ -2,8 +2,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zeth_amd
 ctx = zeth_amd.Context(0); ctx.set_profiling(True)
-for lg in (14, 16, 17, 18, 19, 20, 21):
-    n = (1 << lg) - 1
+for lg in [int(x) for x in sys.argv[1:]] or (14, 16, 17, 18, 19, 20, 21):
+    n = 1 << lg
     bases = zeth_amd.Bases.generate(ctx, 0, 1, n, 12345, 6789)
     sc = zeth_amd.DeviceBuffer.random_scalars(ctx, 0, n, lg)
     row = []

@@ -202,7 +202,21 @@ static __global__ void __launch_bounds__(1024) k_hist(const int16_t* __restrict_
   }
 }
 
-// one block (1024 lanes) per window: exclusive scans of bucket counts and of unit counts
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(x, d);
+    if (lane >= d) x += t;
+  }
+  return x;
+}
+
+// One block (16 waves) per window: exclusive scans of the bucket counts (entry offsets), of the unit counts and of the
+// full-length unit counts, plus the histogram of unit lengths that orders the units longest first.  Each wave scans a
+// contiguous sixteenth of the buckets 64 at a time (coalesced loads and stores, shuffles, no barriers inside), the
+// waves' totals are combined through LDS.
 static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ cnt, size_t n, uint32_t nb, uint32_t L,
                                                 uint32_t cap, uint32_t* __restrict__ cursor /* absolute positions */,
                                                 uint32_t* __restrict__ boff /* bucket start, absolute */,
@@ -213,84 +227,88 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t* __restrict__ pstart /* [W][nhi + 1] */,
                                                 uint32_t* __restrict__ lencur /* [W][1024]: first slot of each unit length */,
                                                 uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */) {
-  __shared__ uint32_t sa[1024], sb[1024], sc[1024], lh[1025];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x;
-  const uint32_t per = (nb + 1023) / 1024;
-  const uint32_t b0 = tid * per;
-  uint32_t ca = 0, cb = 0, cf = 0;
+  __shared__ uint32_t lh[1025], wtot[16][3], lsum[16];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t per_wave = (nb + 15) / 16;
+  const uint32_t lo = wv * per_wave < nb ? wv * per_wave : nb;
+  const uint32_t hi = lo + per_wave < nb ? lo + per_wave : nb;
+  const uint32_t* __restrict__ c = cnt + (size_t)w * nb;
   lh[tid] = 0;
   if (tid == 0) lh[1024] = 0;
   __syncthreads();
-  for (uint32_t j = 0; j < per; j++) {
-    uint32_t b = b0 + j;
-    if (b < nb) {
-      uint32_t v = cnt[(size_t)w * nb + b];
-      ca += v;
-      cb += (v + L - 1) / L;
-      if (v > L) atomicMax(&wunits[gridDim.x], (v + L - 1) / L);
-      cf += v / L;
-      // histogram of unit lengths (1..L <= 1024): v / L full units and one of v % L
-      if (v >= L) atomicAdd(&lh[L], v / L);
-      if (v % L) atomicAdd(&lh[v % L], 1u);
-    }
+  // pass 1: per-wave totals, histogram of unit lengths (1..L <= 1024: v / L full units and one of v % L)
+  uint32_t sa = 0, sb = 0, sc = 0, mx = 0;
+  for (uint32_t b = lo + lane; b < hi; b += 64) {
+    const uint32_t v = c[b];
+    const uint32_t nu = (v + L - 1) / L, fu = v / L;
+    sa += v;
+    sb += nu;
+    sc += fu;
+    mx = nu > mx ? nu : mx;
+    if (fu) atomicAdd(&lh[L], fu);
+    if (v % L) atomicAdd(&lh[v % L], 1u);
+  }
+#pragma unroll
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
+    sa += __shfl_xor(sa, d);
+    sb += __shfl_xor(sb, d);
+    sc += __shfl_xor(sc, d);
+    const uint32_t o = __shfl_xor(mx, d);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) {
+    wtot[wv][0] = sa;
+    wtot[wv][1] = sb;
+    wtot[wv][2] = sc;
+    if (mx > 1) atomicMax(&wunits[gridDim.x], mx);
   }
   __syncthreads();
-  // units are handed to the accumulation kernel longest first (a wave runs as long as its longest lane): slot
-  // ranges per length, descending, from an exclusive scan over the reversed histogram
-  {
-    const uint32_t own = lh[1024 - tid];
-    sa[tid] = own;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-      uint32_t x = tid >= off ? sa[tid - off] : 0;
-      __syncthreads();
-      sa[tid] += x;
-      __syncthreads();
+  // slot ranges of the unit lengths, longest first: exclusive scan over the reversed histogram (bin i = length 1024 - i)
+  const uint32_t own = lh[1024 - tid];
+  const uint32_t hincl = wave_inclusive_scan(own);
+  if (lane == 63) lsum[wv] = hincl;
+  // pass 2: exclusive prefixes
+  uint32_t ea = 0, eb = 0, ef = 0, ta = 0, tb = 0;
+  for (uint32_t q = 0; q < 16; q++) {
+    if (q < wv) {
+      ea += wtot[q][0];
+      eb += wtot[q][1];
+      ef += wtot[q][2];
     }
-    lencur[(size_t)w * 1024 + (1023 - tid)] = sa[tid] - own;  // index = length - 1
-    __syncthreads();
-  }
-  sa[tid] = ca;
-  sb[tid] = cb;
-  sc[tid] = cf;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t xa = 0, xb = 0, xc = 0;
-    if (tid >= off) {
-      xa = sa[tid - off];
-      xb = sb[tid - off];
-      xc = sc[tid - off];
-    }
-    __syncthreads();
-    sa[tid] += xa;
-    sb[tid] += xb;
-    sc[tid] += xc;
-    __syncthreads();
-  }
-  uint32_t ea = sa[tid] - ca, eb = sb[tid] - cb, ef = sc[tid] - cf;  // exclusive prefixes
-  if (tid == 1023) {
-    wunits[w] = sb[1023];
-    if (nhi) pstart[(size_t)w * (nhi + 1) + nhi] = (uint32_t)((size_t)w * n) + sa[1023];
+    ta += wtot[q][0];
+    tb += wtot[q][1];
   }
   const uint32_t abase = (uint32_t)((size_t)w * n);
   const uint32_t ubase = w * cap;
-  for (uint32_t j = 0; j < per; j++) {
-    uint32_t b = b0 + j;
-    if (b < nb) {
-      uint32_t v = cnt[(size_t)w * nb + b];
-      cursor[(size_t)w * nb + b] = abase + ea;
+  for (uint32_t b0 = lo; b0 < hi; b0 += 64) {
+    const uint32_t b = b0 + lane;
+    const uint32_t v = b < hi ? c[b] : 0;
+    const uint32_t nu = (v + L - 1) / L, fu = v / L;
+    const uint32_t ia = wave_inclusive_scan(v), ib = wave_inclusive_scan(nu), ic = wave_inclusive_scan(fu);
+    if (b < hi) {
+      const size_t g = (size_t)w * nb + b;
+      const uint32_t xa = abase + ea + ia - v;
+      cursor[g] = xa;
+      boff[g] = xa;
+      ufirst[g] = ubase + eb + ib - nu;
+      ffirst[g] = ef + ic - fu;
       if (nhi && (b & 255u) == 0) {
-        cursor1[(size_t)w * nhi + (b >> 8)] = abase + ea;
-        pstart[(size_t)w * (nhi + 1) + (b >> 8)] = abase + ea;
+        cursor1[(size_t)w * nhi + (b >> 8)] = xa;
+        pstart[(size_t)w * (nhi + 1) + (b >> 8)] = xa;
       }
-      boff[(size_t)w * nb + b] = abase + ea;
-      ufirst[(size_t)w * nb + b] = ubase + eb;
-      ffirst[(size_t)w * nb + b] = ef;  // full-length units before this bucket: their slots need no atomics
-      ea += v;
-      eb += (v + L - 1) / L;
-      ef += v / L;
     }
+    ea += __shfl(ia, 63);
+    eb += __shfl(ib, 63);
+    ef += __shfl(ic, 63);
   }
+  if (tid == 0) {
+    wunits[w] = tb;
+    if (nhi) pstart[(size_t)w * (nhi + 1) + nhi] = abase + ta;
+  }
+  __syncthreads();
+  uint32_t hoff = 0;
+  for (uint32_t q = 0; q < wv; q++) hoff += lsum[q];
+  lencur[(size_t)w * 1024 + (1023 - tid)] = hoff + hincl - own;  // index = length - 1
 }
 
 static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restrict__ dig, size_t n, uint32_t nb,
@@ -328,17 +346,6 @@ static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restri
 // straight into 2^15 bucket streams writes 4-byte entries to 2^15 different cache lines per block (measured 6.7 ms
 // at 2^24 points); here level 1 splits a tile over <= 128 partitions of 256 buckets (runs of ~128 entries) and level 2
 // finishes each partition on its low 8 bits (runs of ~32 entries), so both levels write in long contiguous runs.
-// inclusive prefix sum across the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
-  const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-  for (uint32_t d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(x, d);
-    if (lane >= d) x += t;
-  }
-  return x;
-}
-
 static constexpr uint32_t SORT_TILE1 = 8192;
 static constexpr uint32_t SORT_TILE2 = 8192;
 
