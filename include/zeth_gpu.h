@@ -185,6 +185,11 @@ int zg_group_sparse_combine(zg_ctx* ctx, int curve, int group, const void* point
                             const uint64_t* row_ptr, const uint32_t* col, const void* coeff, size_t n_rows, int form,
                             void* out_points);
 
+/* Sum of n affine points on the host: the combine step of an MSM sharded by point range, after the ranks' partial
+ * results (one point each) have been all-gathered -- what libff::multi_exp does with the partial sums of its OpenMP
+ * chunks. */
+int zg_host_group_sum(int curve, int group, const void* points, size_t n, int form, void* out_affine);
+
 /* libff's G::is_well_formed() over n affine points (the identity, or Y^2 = X^3 + b), on the host: what
  * groth16_snark<ppT>::proving_key_read_bytes runs on a key it has just read
  * (libzeth/snarks/groth16/groth16_snark.tcc:145-147, 193-213).  *first_bad = n when every point passes, else the

@@ -50,7 +50,8 @@ sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
 import torch.distributed as dist
 import cpu_oracle
 from zeth_model import BN254 as C
-from zeth_amd.distributed import all_gather_sum, shard_range
+from zeth_amd.distributed import all_gather_sum, all_gather_sum_bytes, shard_range
+from zeth_amd.lib import decode_point, encode_point
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 rng = random.Random(99)
@@ -65,6 +66,10 @@ first, count = shard_range(n, world, rank)
 part = cpu_oracle.msm(0, 1, pts[first:first + count], sc[first:first + count])
 total = all_gather_sum(0, 1, part, "cpu")
 assert total == cpu_oracle.msm(0, 1, pts, sc), rank
+# the raw-bytes exchange bench.py uses per step (one zg_host_group_sum call for the combine)
+raw = all_gather_sum_bytes(0, 1, encode_point(0, 1, part), "cpu")
+assert decode_point(0, 1, raw) == total, rank
+assert decode_point(0, 1, all_gather_sum_bytes(0, 1, encode_point(0, 1, pts[0] if rank == 0 else G.neg(pts[0])), "cpu")) is None
 # cancelling partials: rank 0 holds P, rank 1 holds -P
 total = all_gather_sum(0, 1, pts[0] if rank == 0 else G.neg(pts[0]), "cpu")
 assert total is None

@@ -454,6 +454,12 @@ int zg_group_sparse_combine(zg_ctx* ctx, int curve, int group, const void* point
   return ops->group_combine(ctx, points, n_points, row_ptr, col, coeff, n_rows, form, out_points);
 }
 
+int zg_host_group_sum(int curve, int group, const void* points, size_t n, int form, void* out_affine) {
+  const GroupOps* ops = zg_group_ops(curve, group);
+  if (!ops || (n && !points) || !out_affine || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;
+  return ops->host_sum(points, n, form, out_affine);
+}
+
 int zg_host_points_check(int curve, int group, const void* points, size_t n, int form, size_t* first_bad) {
   const GroupOps* ops = zg_group_ops(curve, group);
   if (!ops || (n && !points) || !first_bad || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;

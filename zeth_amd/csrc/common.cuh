@@ -145,6 +145,7 @@ struct GroupOps {
   int (*group_scale)(zg_ctx*, void* points, size_t n, const uint32_t* k_plain, int form);
   int (*group_combine)(zg_ctx*, const void* points, size_t n_points, const uint64_t* row_ptr, const uint32_t* col,
                        const void* coeff_plain, size_t n_rows, int form, void* out_points);
+  int (*host_sum)(const void* pts, size_t n, int form, void* out_affine);
 };
 
 const GroupOps* zg_group_ops(int curve, int group);

@@ -386,6 +386,24 @@ void host_convert_thunk(void* pts, size_t n, int to_mont) {
   host_affine_convert(reinterpret_cast<Affine<F>*>(pts), n, to_mont);
 }
 
+// sum of n affine points on the host (one normalisation): the combine step of a point-range sharded MSM, after the
+// ranks' partial results have been all-gathered
+template <class F>
+int host_group_sum(const void* pts, size_t n, int form, void* out) {
+  const char* src = reinterpret_cast<const char*>(pts);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (size_t i = 0; i < n; i++) {
+    Affine<F> p;
+    memcpy(&p, src + i * sizeof(p), sizeof(p));
+    if (form == ZG_FORM_PLAIN) host_affine_convert(&p, 1, 1);
+    xyzz_madd(acc, p);
+  }
+  Affine<F> o = xyzz_to_affine(acc);
+  if (form == ZG_FORM_PLAIN) host_affine_convert(&o, 1, 0);
+  memcpy(out, &o, sizeof(o));
+  return ZG_OK;
+}
+
 // libff's G::is_well_formed() on affine input: the identity, or Y^2 = X^3 + b (host only; used by the key loader
 // the way groth16_snark.tcc:193-224 checks a proving key after reading it).  *first_bad = n when all points pass.
 template <class F, class Gen>
@@ -462,6 +480,7 @@ struct G2Gen {
                                 &zg::host_points_check<F, GEN>,                                   \
                                 &zg::group_fft<F, FR>,                                            \
                                 &zg::group_scale<F, FR>,                                          \
-                                &zg::group_combine<F, FR>};                                       \
+                                &zg::group_combine<F, FR>,                                        \
+                                &zg::host_group_sum<F>};                                          \
     return &ops;                                                                                  \
   }

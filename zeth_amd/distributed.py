@@ -35,3 +35,19 @@ def all_gather_sum(curve: int, group: int, partial, device: str = "cuda"):
     for g in range(world):
         acc = _lib.host_group_op(curve, group, "add", acc, _lib.decode_point(curve, group, raw[nbytes * g : nbytes * (g + 1)]))
     return acc
+
+
+def all_gather_sum_bytes(curve: int, group: int, partial: bytes, device: str = "cuda") -> bytes:
+    """The same exchange on raw affine bytes (plain form, all-zero = identity) with one host call for the sum: the
+    per-step path of bench.py, where the exchange must not cost more than a few tens of microseconds of host time."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return partial
+    world = dist.get_world_size()
+    nbytes = _lib.affine_bytes(curve, group)
+    mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(device)
+    out = torch.empty(nbytes * world, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return _lib.host_group_sum(curve, group, out.cpu().numpy().tobytes(), world)

@@ -87,6 +87,7 @@ def load_library():
     L.zg_prove.argtypes = [vp, vp, sz, vp, sz, ci, vp, vp, ci, vp]
     L.zg_witness_map.argtypes = [vp, vp, sz, vp, sz, ci, ci, vp]
     L.zg_host_group_op.argtypes = [ci, ci, ci, vp, vp, ci, vp]
+    L.zg_host_group_sum.argtypes = [ci, ci, vp, sz, ci, vp]
     L.zg_host_points_check.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(sz)]
     L.zg_group_fft.argtypes = [vp, ci, ci, vp, ctypes.c_uint, ci, ci]
     L.zg_group_scale.argtypes = [vp, ci, ci, vp, sz, vp, ci]
@@ -286,6 +287,13 @@ class Bases:
             cbuf = ctypes.create_string_buffer(bytes(buf), len(buf)) if cnt else None
             _check(self._L.zg_msm_ex(self._h, first, cbuf, cnt, form, MEM_HOST, FORM_PLAIN, out, window_bits))
         return decode_point(self.curve, self.group, out.raw)
+
+    def msm_bytes(self, scalars: "DeviceBuffer", n: int, first: int = 0, form: int = FORM_PLAIN) -> bytes:
+        """zg_msm on device-resident scalars; the affine result as raw bytes (plain form): the fast path of the
+        sharded benchmark, no integer decoding."""
+        out = ctypes.create_string_buffer(affine_bytes(self.curve, self.group))
+        _check(self._L.zg_msm(self._h, first, ctypes.c_void_p(scalars.ptr), n, form, MEM_DEVICE, FORM_PLAIN, out))
+        return out.raw
 
     def free(self):
         if self._h:
@@ -493,3 +501,12 @@ def group_sparse_combine(ctx: Context, curve: int, group: int, points: Sequence,
     out = ctypes.create_string_buffer(max(1, len(rows) * affine_bytes(curve, group)))
     _check(ctx._L.zg_group_sparse_combine(ctx._h, curve, group, pbuf, n, rp, col, val, len(rows), FORM_PLAIN, out))
     return _decode_points(curve, group, out.raw, len(rows))
+
+
+def host_group_sum(curve: int, group: int, raw: bytes, n: int) -> bytes:
+    """Sum of n affine points given as raw plain-form bytes (zg_host_group_sum) -> raw bytes."""
+    ab = affine_bytes(curve, group)
+    assert len(raw) == n * ab
+    out = ctypes.create_string_buffer(ab)
+    _check(load_library().zg_host_group_sum(curve, group, raw, n, FORM_PLAIN, out))
+    return out.raw
