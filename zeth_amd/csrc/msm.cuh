@@ -29,6 +29,11 @@ namespace zg {
 static constexpr int MSM_MAX_C = 16;
 static constexpr uint32_t COMBINE_SERIAL_MAX = 8;  // units folded serially by the first unit's lane; more: tree (k_combine_tree)
 static constexpr uint32_t COMBINE_CHUNK = 512;     // units per workgroup and launch of the tree
+// Units are handed to the accumulation kernel longest first, by length class: class UNIT_CLASSES = full-length units,
+// classes 0..127 = partial units by len * 128 / L (lengths within a class differ by < L / 128, under 1 % of a wave's run)
+static constexpr uint32_t UNIT_CLASSES = 128;
+static constexpr uint32_t UNIT_CLASS_STRIDE = 256;
+__host__ __device__ inline uint32_t unit_class(uint32_t len, uint32_t L) { return ((len - 1) * UNIT_CLASSES) / L; }
 static constexpr int MSM_MAX_W = 48;
 
 struct AddConst {
@@ -225,18 +230,17 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t nhi /* partitions of 256 buckets (0: single-level sort) */,
                                                 uint32_t* __restrict__ cursor1 /* [W][nhi] */,
                                                 uint32_t* __restrict__ pstart /* [W][nhi + 1] */,
-                                                uint32_t* __restrict__ lencur /* [W][1024]: first slot of each unit length */,
+                                                uint32_t* __restrict__ lencur /* [W][UNIT_CLASS_STRIDE]: first slot of each length class */,
                                                 uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */) {
-  __shared__ uint32_t lh[1025], wtot[16][3], lsum[16];
+  __shared__ uint32_t lh[UNIT_CLASSES + 1], wtot[16][3];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t per_wave = (nb + 15) / 16;
   const uint32_t lo = wv * per_wave < nb ? wv * per_wave : nb;
   const uint32_t hi = lo + per_wave < nb ? lo + per_wave : nb;
   const uint32_t* __restrict__ c = cnt + (size_t)w * nb;
-  lh[tid] = 0;
-  if (tid == 0) lh[1024] = 0;
+  if (tid <= UNIT_CLASSES) lh[tid] = 0;
   __syncthreads();
-  // pass 1: per-wave totals, histogram of unit lengths (1..L <= 1024: v / L full units and one of v % L)
+  // pass 1: per-wave totals, histogram of unit length classes (v / L full units and one partial unit of v % L)
   uint32_t sa = 0, sb = 0, sc = 0, mx = 0;
   for (uint32_t b = lo + lane; b < hi; b += 64) {
     const uint32_t v = c[b];
@@ -245,8 +249,8 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
     sb += nu;
     sc += fu;
     mx = nu > mx ? nu : mx;
-    if (fu) atomicAdd(&lh[L], fu);
-    if (v % L) atomicAdd(&lh[v % L], 1u);
+    if (fu) atomicAdd(&lh[UNIT_CLASSES], fu);
+    if (v % L) atomicAdd(&lh[unit_class(v % L, L)], 1u);
   }
 #pragma unroll
   for (uint32_t d = 32; d >= 1; d >>= 1) {
@@ -263,10 +267,12 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
     if (mx > 1) atomicMax(&wunits[gridDim.x], mx);
   }
   __syncthreads();
-  // slot ranges of the unit lengths, longest first: exclusive scan over the reversed histogram (bin i = length 1024 - i)
-  const uint32_t own = lh[1024 - tid];
-  const uint32_t hincl = wave_inclusive_scan(own);
-  if (lane == 63) lsum[wv] = hincl;
+  // slot ranges of the length classes, longest first (full-length units, then the partial classes from longest to shortest)
+  if (tid <= UNIT_CLASSES) {
+    uint32_t before = 0;
+    for (uint32_t q = tid + 1; q <= UNIT_CLASSES; q++) before += lh[q];
+    lencur[(size_t)w * UNIT_CLASS_STRIDE + tid] = before;
+  }
   // pass 2: exclusive prefixes
   uint32_t ea = 0, eb = 0, ef = 0, ta = 0, tb = 0;
   for (uint32_t q = 0; q < 16; q++) {
@@ -305,10 +311,6 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
     wunits[w] = tb;
     if (nhi) pstart[(size_t)w * (nhi + 1) + nhi] = abase + ta;
   }
-  __syncthreads();
-  uint32_t hoff = 0;
-  for (uint32_t q = 0; q < wv; q++) hoff += lsum[q];
-  lencur[(size_t)w * 1024 + (1023 - tid)] = hoff + hincl - own;  // index = length - 1
 }
 
 static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restrict__ dig, size_t n, uint32_t nb,
@@ -464,17 +466,14 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
 // Unit table and the longest-first order.  k_units: one lane per bucket writes the bucket's first COMBINE_SERIAL_MAX
 // units and lists the bucket as heavy when it has more; k_units_heavy: the remaining units of the heavy buckets,
 // one lane each (a bucket holding half of all entries -- the "1" scalars of a witness -- has thousands).
-// Slots of the order: full-length units are ranked by a scan (no atomics), the one partial unit of a bucket claims its
-// slot in its length class atomically.
-__device__ __forceinline__ void emit_unit(uint32_t k, uint32_t g, uint32_t w, uint32_t v, uint32_t u0, uint32_t start,
-                                          uint32_t full_rank, uint32_t L, uint32_t cap, UnitDesc* __restrict__ units,
-                                          uint32_t* __restrict__ lencur, uint32_t* __restrict__ order) {
-  const uint32_t rest = v - k * L;
-  const uint32_t len = rest < L ? rest : L;
-  units[u0 + k] = UnitDesc{(uint64_t)start + (uint64_t)k * L, len, g};
-  uint32_t* slots = order + (size_t)w * cap;
-  if (len == L) slots[lencur[(size_t)w * 1024 + (L - 1)] + full_rank + k] = u0 + k;
-  else slots[atomicAdd(&lencur[(size_t)w * 1024 + (len - 1)], 1u)] = u0 + k;
+// Slots of the order: full-length units are ranked by a scan (no atomics); the one partial unit of a bucket takes a
+// slot of its length class, claimed per workgroup through LDS (one global atomic per class and workgroup: the
+// same-address atomics of 2^15 buckets per window on ~100 counters were 0.1 ms).
+__device__ __forceinline__ void emit_full_unit(uint32_t k, uint32_t g, uint32_t w, uint32_t u0, uint32_t start,
+                                               uint32_t full_rank, uint32_t L, uint32_t cap, UnitDesc* __restrict__ units,
+                                               const uint32_t* __restrict__ lencur, uint32_t* __restrict__ order) {
+  units[u0 + k] = UnitDesc{(uint64_t)start + (uint64_t)k * L, L, g};
+  order[(size_t)w * cap + lencur[(size_t)w * UNIT_CLASS_STRIDE + UNIT_CLASSES] + full_rank + k] = u0 + k;
 }
 
 static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
@@ -483,16 +482,38 @@ static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict
                                                 UnitDesc* __restrict__ units, uint32_t* __restrict__ lencur,
                                                 uint32_t* __restrict__ order /* [W][cap]: unit ids, longest first */,
                                                 uint32_t* __restrict__ heavy /* [0] = count, then ids of heavy buckets */) {
+  __shared__ uint32_t lc[UNIT_CLASSES], gb[UNIT_CLASSES];
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)nb * W) return;
-  const uint32_t v = cnt[g];
-  if (!v) return;
-  const uint32_t w = (uint32_t)(g / nb);
-  const uint32_t nu = (v + L - 1) / L;
-  if (nu > COMBINE_SERIAL_MAX) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)g;
-  const uint32_t u0 = ufirst[g], start = boff[g], fr = ffirst[g];
-  const uint32_t mine = nu < COMBINE_SERIAL_MAX ? nu : COMBINE_SERIAL_MAX;
-  for (uint32_t k = 0; k < mine; k++) emit_unit(k, (uint32_t)g, w, v, u0, start, fr, L, cap, units, lencur, order);
+  const bool in_range = g < (size_t)nb * W;
+  const bool one_window = (nb % 256u) == 0;  // then the 256 buckets of this workgroup share a window
+  const uint32_t v = in_range ? cnt[g] : 0;
+  const uint32_t w = in_range ? (uint32_t)(g / nb) : 0;
+  const uint32_t full = v / L, rem = v % L;
+  const uint32_t u0 = v ? ufirst[g] : 0, start = v ? boff[g] : 0, fr = v ? ffirst[g] : 0;
+  if (threadIdx.x < UNIT_CLASSES) lc[threadIdx.x] = 0;
+  __syncthreads();
+  if (v) {
+    if (full + (rem ? 1 : 0) > COMBINE_SERIAL_MAX) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)g;
+    const uint32_t mine = full < COMBINE_SERIAL_MAX ? full : COMBINE_SERIAL_MAX;
+    for (uint32_t k = 0; k < mine; k++) emit_full_unit(k, (uint32_t)g, w, u0, start, fr, L, cap, units, lencur, order);
+  }
+  // the partial unit (index `full`), unless it belongs to k_units_heavy
+  const bool partial = v && rem && full < COMBINE_SERIAL_MAX;
+  const uint32_t cls = partial ? unit_class(rem, L) : 0;
+  uint32_t rank = 0;
+  if (partial && one_window) rank = atomicAdd(&lc[cls], 1u);
+  __syncthreads();
+  if (one_window && threadIdx.x < UNIT_CLASSES) {
+    const uint32_t c = lc[threadIdx.x];
+    const uint32_t wb = (uint32_t)(((size_t)blockIdx.x * blockDim.x) / nb);
+    gb[threadIdx.x] = c ? atomicAdd(&lencur[(size_t)wb * UNIT_CLASS_STRIDE + threadIdx.x], c) : 0;
+  }
+  __syncthreads();
+  if (partial) {
+    const uint32_t slot = one_window ? gb[cls] + rank : atomicAdd(&lencur[(size_t)w * UNIT_CLASS_STRIDE + cls], 1u);
+    units[u0 + full] = UnitDesc{(uint64_t)start + (uint64_t)full * L, rem, (uint32_t)g};
+    order[(size_t)w * cap + slot] = u0 + full;
+  }
 }
 
 static __global__ void __launch_bounds__(256) k_units_heavy(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff,
@@ -504,10 +525,17 @@ static __global__ void __launch_bounds__(256) k_units_heavy(const uint32_t* __re
   for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
     const uint32_t g = heavy[1 + hi];
     const uint32_t v = cnt[g], w = g / nb;
-    const uint32_t nu = (v + L - 1) / L;
+    const uint32_t full = v / L, rem = v % L;
+    const uint32_t nu = full + (rem ? 1 : 0);
     const uint32_t u0 = ufirst[g], start = boff[g], fr = ffirst[g];
-    for (uint32_t k = COMBINE_SERIAL_MAX + blockIdx.x * blockDim.x + threadIdx.x; k < nu; k += gridDim.x * blockDim.x)
-      emit_unit(k, g, w, v, u0, start, fr, L, cap, units, lencur, order);
+    for (uint32_t k = COMBINE_SERIAL_MAX + blockIdx.x * blockDim.x + threadIdx.x; k < nu; k += gridDim.x * blockDim.x) {
+      if (k < full) {
+        emit_full_unit(k, g, w, u0, start, fr, L, cap, units, lencur, order);
+      } else {
+        units[u0 + k] = UnitDesc{(uint64_t)start + (uint64_t)k * L, rem, g};
+        order[(size_t)w * cap + atomicAdd(&lencur[(size_t)w * UNIT_CLASS_STRIDE + unit_class(rem, L)], 1u)] = u0 + k;
+      }
+    }
   }
 }
 
@@ -557,7 +585,7 @@ __device__ __forceinline__ void xyzz_madd_wave(XYZZ<F>& acc, const Affine<F>& p)
 #define ZG_ACCUM_MIN_WAVES 1
 #endif
 #ifndef ZG_ACCUM_BLOCK
-#define ZG_ACCUM_BLOCK 256
+#define ZG_ACCUM_BLOCK 128
 #endif
 template <class F>
 __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
