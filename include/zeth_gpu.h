@@ -85,6 +85,17 @@ int zg_bases_batch_exp(zg_ctx* ctx, int curve, int group, const void* scalars, s
 int zg_bases_count(const zg_bases* b, size_t* n);
 /* copy `count` points starting at `first` back to the host (affine, `form`) */
 int zg_bases_read(zg_bases* b, size_t first, size_t count, int form, void* out);
+/* Fixed-base table.  No counterpart in the reference (libff::multi_exp recomputes from the bare bases every time);
+ * it exists because the bases of a proving key never change (libsnark r1cs_gg_ppzksnark_proving_key's A/B/H/L queries,
+ * loaded once at prover_server.cpp:449-493) and HBM is large: the library keeps the multiples 2^(j*c) P_i, j < D =
+ * ceil((bits + 2) / c), of every base, so that an MSM sorts all n*D digit terms into ONE set of 2^(c-1) buckets and
+ * needs D = 12 mixed additions per 254-bit scalar at c = 22 instead of 16-17.  Costs D times the base memory (12.9 GB
+ * for 2^24 BN254 G1 points) and one pass of D*c doublings per base.  window_bits: 0 = chosen from the number of bases,
+ * else 10..22.  Results of zg_msm are unchanged (same group element); zg_bases_read still returns the bases.
+ * Calling it again is a no-op (ZG_ERR_INVALID_ARGUMENT if a different width is asked for). */
+int zg_bases_precompute(zg_bases* b, int window_bits);
+/* *window_bits = *levels = 0 when the set has no table */
+int zg_bases_table_info(const zg_bases* b, int* window_bits, int* levels);
 void zg_bases_free(zg_bases* b);
 
 /* sum_{i<n} scalars[i] * bases[first + i]  ->  one affine point.

@@ -17,13 +17,18 @@ MAC = {(0, 1): 21760, (0, 2): 65280, (1, 1): 48000, (1, 2): 144000}
 PEAK = 3.85e13
 
 
-def msm_case(ctx, cid, gid, lg, reps=3, check=True):
+def msm_case(ctx, cid, gid, lg, reps=3, check=True, table=None):
     C = BN254 if cid == 0 else BLS12_377
     G = C.G1 if gid == 1 else C.G2
     n = 1 << lg
     t0, d = 0x1234567890ABCDEF1234567, 0xFEDCBA987654321
     bases = zeth_amd.Bases.generate(ctx, cid, gid, n, t0, d)
     sc = zeth_amd.DeviceBuffer.random_scalars(ctx, cid, n, lg)
+    build_s = None
+    if table is not None:
+        t = time.perf_counter()
+        bases.precompute(table)
+        build_s = time.perf_counter() - t
     times = []
     res = None
     for _ in range(reps + 1):
@@ -35,12 +40,17 @@ def msm_case(ctx, cid, gid, lg, reps=3, check=True):
     ok = None
     if check:
         ok = res == G.mul(closed_form_scalar(random_scalars_host(n, C.r, lg), t0, d, C.r), G.gen)
+    tinfo = bases.table_info() if table is not None else None
     bases.free()
     sc.free()
     ms = times[len(times) // 2] * 1e3
     out = {"op": "msm", "curve": C.name, "group": "G%d" % gid, "log_n": lg, "ms": ms, "points_per_s": n / (ms * 1e-3),
            "accum_ms": ph.get("accum"), "mac_frac_whole_call": n * MAC[(cid, gid)] / (ms * 1e-3) / PEAK,
            "mac_frac_accum": n * MAC[(cid, gid)] / (ph["accum"] * 1e-3) / PEAK, "verified": ok, "phases_ms": ph}
+    if table is not None:
+        c, D = tinfo
+        out.update({"table": {"window_bits": c, "levels": D, "build_s": build_s}})
+        out["mac_frac_accum"] = None  # the per-point MAC count of SURVEY 8d assumes 16-17 digits per scalar
     print(json.dumps(out), flush=True)
 
 
@@ -80,6 +90,15 @@ def main():
     if which in ("all", "g1"):
         for lg in range(16, 27):
             msm_case(ctx, 0, 1, lg)
+    if which == "g1t":  # fixed-base table mode; optional digit width and sizes
+        cw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+        sizes = [int(a) for a in sys.argv[3:]] or list(range(16, 27))
+        for lg in sizes:
+            msm_case(ctx, 0, 1, lg, table=cw)
+    if which == "othert":
+        msm_case(ctx, 0, 2, 22, table=0)
+        msm_case(ctx, 1, 1, 22, table=0)
+        msm_case(ctx, 1, 2, 20, table=0)
     if which in ("all", "other"):
         msm_case(ctx, 0, 2, 22)
         msm_case(ctx, 1, 1, 22)

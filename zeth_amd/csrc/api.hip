@@ -289,6 +289,43 @@ int zg_bases_read(zg_bases* b, size_t first, size_t count, int form, void* out) 
   return ZG_OK;
 }
 
+int zg_bases_precompute(zg_bases* b, int window_bits) {
+  if (!b) return ZG_ERR_INVALID_ARGUMENT;
+  int c = 0, D = 0;
+  ZG_TRY(b->ops->table_params(b->n, window_bits, &c, &D));
+  if (b->table_D) return b->table_c == c || window_bits == 0 ? ZG_OK : ZG_ERR_INVALID_ARGUMENT;
+  if (b->n == 0) return ZG_OK;
+  if ((uint64_t)D * (uint64_t)b->n >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 31-bit table indices in the sort's entries
+  zg_ctx* ctx = b->ctx;
+  ZG_HIP(hipSetDevice(ctx->device));
+  void* table = nullptr;
+  const size_t level = b->n * b->ops->affine_bytes;
+  if (hipMalloc(&table, level * (size_t)D) != hipSuccess) {
+    (void)hipGetLastError();
+    return ZG_ERR_OUT_OF_MEMORY;
+  }
+  int s = ZG_OK;
+  if (hipMemcpyAsync(table, b->d_pts, level, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) s = ZG_ERR_HIP;
+  if (s == ZG_OK) s = b->ops->table_build(ctx, table, b->n, c, D);
+  if (s != ZG_OK) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(table);
+    return s;
+  }
+  hipFree(b->d_pts);
+  b->d_pts = table;
+  b->table_c = c;
+  b->table_D = D;
+  return ZG_OK;
+}
+
+int zg_bases_table_info(const zg_bases* b, int* window_bits, int* levels) {
+  if (!b || !window_bits || !levels) return ZG_ERR_INVALID_ARGUMENT;
+  *window_bits = b->table_c;
+  *levels = b->table_D;
+  return ZG_OK;
+}
+
 void zg_bases_free(zg_bases* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
@@ -318,8 +355,14 @@ int zg_msm_ex(zg_bases* b, size_t first, const void* scalars, size_t n, int scal
   } else if (scalars_mem != ZG_MEM_DEVICE && scalars_mem != ZG_MEM_HOST) {
     return ZG_ERR_INVALID_ARGUMENT;
   }
-  int s = b->ops->msm(ctx, (const char*)b->d_pts + first * b->ops->affine_bytes, d_scalars, n,
-                      scalar_form == ZG_FORM_MONT, window_bits, out_form, out_affine);
+  int s;
+  if (b->table_D) {
+    const MsmTable tab{b->n, first, b->table_c, b->table_D};
+    s = b->ops->msm(ctx, b->d_pts, d_scalars, n, scalar_form == ZG_FORM_MONT, window_bits, out_form, out_affine, &tab);
+  } else {
+    s = b->ops->msm(ctx, (const char*)b->d_pts + first * b->ops->affine_bytes, d_scalars, n, scalar_form == ZG_FORM_MONT,
+                    window_bits, out_form, out_affine, nullptr);
+  }
   if (staged) {
     hipStreamSynchronize(ctx->stream);
     hipFree(staged);

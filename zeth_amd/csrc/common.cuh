@@ -51,6 +51,7 @@ struct zg_ctx {
   size_t pinned_cap = 0;
   size_t job_n = 0;
   int job_W = 0, job_c = 0;
+  int job_table_shift = -1;  // >= 0: the job ran in fixed-base table mode with 2^shift buckets per group
   bool want_dense = false;  // count scalars other than 0/1 during recoding (prover lanes)
   uint32_t job_dense = 0;  // scalars other than 0/1 seen by the last MSM on this context
   int pinned_reserve(size_t bytes) {
@@ -122,15 +123,22 @@ struct zg_ctx {
   }
 };
 
+// fixed-base table behind a set of bases (msm_table.cuh): D levels of N points, level j = 2^(j c) * level 0
+struct MsmTable {
+  size_t N, first;  // points per level; first base of the MSM's range
+  int c, D;
+};
+
 struct GroupOps {
   size_t affine_bytes;
   size_t fq_limbs;  // limbs per coordinate-field base element
   int coords;       // field elements per affine point (2 for G1, 4 for G2)
   // d_pts: device affine points (Montgomery).  d_scalars: device Fr elements.
   int (*msm)(zg_ctx*, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
-             int out_form, void* out_affine_host);
+             int out_form, void* out_affine_host, const MsmTable* tab);
   // the same split in two: queue on the context's stream / wait + host tail (contexts run concurrently)
-  int (*msm_launch)(zg_ctx*, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c);
+  int (*msm_launch)(zg_ctx*, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
+                    const MsmTable* tab);
   int (*msm_finish)(zg_ctx*, int out_form, void* out_affine_host);
   int (*to_mont)(zg_ctx*, void* d_pts, size_t n);  // plain -> Montgomery in place
   int (*generate)(zg_ctx*, void* d_pts, size_t n, const uint32_t* t0, const uint32_t* d);
@@ -146,6 +154,8 @@ struct GroupOps {
   int (*group_combine)(zg_ctx*, const void* points, size_t n_points, const uint64_t* row_ptr, const uint32_t* col,
                        const void* coeff_plain, size_t n_rows, int form, void* out_points);
   int (*host_sum)(const void* pts, size_t n, int form, void* out_affine);
+  int (*table_build)(zg_ctx*, void* d_table, size_t N, int c, int D);
+  int (*table_params)(size_t N, int window_bits, int* c, int* D);
 };
 
 const GroupOps* zg_group_ops(int curve, int group);
@@ -178,6 +188,7 @@ struct zg_bases {
   zg_ctx* ctx;
   int curve, group;
   size_t n;
-  void* d_pts;
+  void* d_pts;  // n points, or table_D levels of n points once zg_bases_precompute has run
   const GroupOps* ops;
+  int table_c = 0, table_D = 0;
 };

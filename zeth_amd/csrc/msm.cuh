@@ -56,12 +56,31 @@ struct MsmPlan {
   uint32_t T;      // bucket segments per window (reduce1 lanes per window)
   uint32_t k;      // buckets per segment
   AddConst K;
+  // fixed-base table mode (msm_make_table_plan): c = digit width (up to 22), D = digits per scalar, all digits share ONE
+  // set of 2^(c-1) buckets, cut into W "bucket groups" of nb <= 2^15 buckets that the sort, the unit table, the
+  // accumulation and the reduction treat the way they treat the windows of the plain mode; E = n * D entries
+  int table, D, shift;
+  size_t E;
 };
 
 inline int ilog2_floor(size_t n) {
   int l = 0;
   while ((n >> (l + 1)) != 0) l++;
   return l;
+}
+
+// The multiples 2^(j c) P_i, j < D, of a fixed-base table: D for a scalar field of `scalar_bits` bits
+inline int msm_table_digits(int scalar_bits, int c) { return (scalar_bits + 2 + c - 1) / c; }
+static constexpr int MSM_TABLE_MIN_C = 10, MSM_TABLE_MAX_C = 22;
+
+// digit width of the table for N fixed bases: about log2(N) - 1 (accumulation n * D mixed additions against a
+// reduction of 2^c additions), at most 22 (128 bucket groups of 2^15 would be the next step: not worth 1/12 fewer digits)
+inline int msm_table_pick_c(size_t N) {
+  int lg = ilog2_floor(N ? N : 1) + ((N & (N - 1)) ? 1 : 0);
+  int c = lg - 1;
+  if (c < 12) c = 12;
+  if (c > MSM_TABLE_MAX_C) c = MSM_TABLE_MAX_C;
+  return c;
 }
 
 // window width for n scalars that are not 0 or 1, tuned on MI355X (tools/tune_c.py): odd widths keep the
@@ -121,9 +140,92 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   return p;
 }
 
+inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
+  MsmPlan p{};
+  p.n = n;
+  p.table = 1;
+  p.c = c;
+  p.D = D;
+  p.E = n * (size_t)D;
+  const int bucket_bits = c - 1;
+  p.shift = bucket_bits < 15 ? bucket_bits : 15;
+  p.nb = 1u << p.shift;
+  p.W = 1 << (bucket_bits - p.shift);
+  size_t L = p.E >> 18;
+  if (L < 32) L = 32;
+  if (L > 1024) L = 1024;
+  if (const char* e = getenv("ZG_MSM_UNIT_LEN")) {
+    size_t v = strtoul(e, nullptr, 0);
+    if (v >= 1 && v <= 1024) L = v;
+  }
+  p.L = (uint32_t)L;
+  // any group may hold all entries (skewed scalars), so every group's slot range is sized for that
+  p.cap = p.nb + (uint32_t)(p.E / L) + 1;
+  size_t per_group = p.E / (size_t)p.W;
+  uint32_t nchunk = (uint32_t)((per_group + (1u << 16) - 1) >> 16);
+  if (nchunk < 1) nchunk = 1;
+  uint32_t maxchunk = 512u / (uint32_t)p.W;
+  if (maxchunk < 1) maxchunk = 1;
+  if (nchunk > maxchunk) nchunk = maxchunk;
+  p.nchunk = nchunk;
+  p.T = p.nb < 1024 ? p.nb : (p.nb >= 32768 ? 2048 : 1024);
+  if (const char* e = getenv("ZG_MSM_SEGMENTS")) {
+    uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
+    if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) p.T = v;
+  }
+  p.k = p.nb / p.T;
+  for (int i = 0; i < 9; i++) p.K.k[i] = 0;
+  for (int w = 0; w < D; w++) {
+    int bit = w * c + (c - 1);
+    p.K.k[bit / 32] |= 1u << (bit % 32);
+  }
+  (void)scalar_bits;
+  return p;
+}
+
 // ---------------------------------------------------------------------------------------------
 // scalar recoding
 // ---------------------------------------------------------------------------------------------
+// signed digits d_j in [-2^(c-1), 2^(c-1)), sum_j d_j 2^(j c) = s, by adding K = sum_j 2^(j c + c - 1) first; emit(j, d)
+template <class Fr, class Emit>
+__device__ __forceinline__ void recode_scalar(const uint32_t* __restrict__ scalars, size_t i, int mont, int c, int D,
+                                              const AddConst& K, bool* dense, Emit emit) {
+  Fr s;
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  uint4 lo = sp[0], hi = sp[1];
+  s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+  s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+  if (mont) s = Fr::from_mont(s);
+  uint32_t hi_bits = s.v[0] >> 1;
+#pragma unroll
+  for (int j = 1; j < 8; j++) hi_bits |= s.v[j];
+  *dense = hi_bits != 0;
+  uint32_t t[9];
+  uint64_t cy = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    cy += (uint64_t)s.v[j] + K.k[j];
+    t[j] = (uint32_t)cy;
+    cy >>= 32;
+  }
+  t[8] = (uint32_t)cy + K.k[8];
+  const uint32_t mask = (1u << c) - 1u;
+  const int half = 1 << (c - 1);
+  uint64_t buf = 0;
+  int have = 0, w = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    buf |= (uint64_t)t[j] << have;
+    have += 32;
+    while (have >= c && w < D) {
+      emit(w, (int)(buf & mask) - half);
+      buf >>= c;
+      have -= c;
+      w++;
+    }
+  }
+}
+
 template <class Fr>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
                                                  int W, AddConst K, int16_t* __restrict__ dig,
@@ -231,7 +333,8 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t* __restrict__ cursor1 /* [W][nhi] */,
                                                 uint32_t* __restrict__ pstart /* [W][nhi + 1] */,
                                                 uint32_t* __restrict__ lencur /* [W][UNIT_CLASS_STRIDE]: first slot of each length class */,
-                                                uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */) {
+                                                uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */,
+                                                const uint32_t* __restrict__ gstart /* table mode: first entry of each bucket group; else null */) {
   __shared__ uint32_t lh[UNIT_CLASSES + 1], wtot[16][3];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t per_wave = (nb + 15) / 16;
@@ -284,7 +387,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
     ta += wtot[q][0];
     tb += wtot[q][1];
   }
-  const uint32_t abase = (uint32_t)((size_t)w * n);
+  const uint32_t abase = gstart ? gstart[w] : (uint32_t)((size_t)w * n);
   const uint32_t ubase = w * cap;
   for (uint32_t b0 = lo; b0 < hi; b0 += 64) {
     const uint32_t b = b0 + lane;
@@ -686,7 +789,8 @@ __global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict
 template <class F>
 __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
                                                   const XYZZ<F>* __restrict__ part, uint32_t nb, uint32_t T, uint32_t k,
-                                                  uint32_t L, uint32_t W, XYZZ<F>* __restrict__ seg) {
+                                                  uint32_t L, uint32_t W, XYZZ<F>* __restrict__ seg,
+                                                  XYZZ<F>* __restrict__ seg_plain /* table mode: unweighted segment sums; else null */) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= T * W) return;
   uint32_t w = g / T, j = g % T;
@@ -707,12 +811,13 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
     xyzz_add_inl(tot, r);
   }
   seg[g] = tot;
+  if (seg_plain) seg_plain[g] = run;
 }
 
 // one block of T lanes per window: tree-sum seg[w*T .. w*T+T) into seg[w*T]
 template <class F>
 __global__ void __launch_bounds__(1024) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
-  XYZZ<F>* s = seg + (size_t)blockIdx.x * T;
+  XYZZ<F>* s = seg + (size_t)blockIdx.x * T;  // (table mode: the unweighted sums follow as gridDim.x / 2 more rows)
   if (T > blockDim.x) {  // fold the tail onto the first blockDim entries
     XYZZ<F> a = s[threadIdx.x];
     for (uint32_t j = threadIdx.x + blockDim.x; j < T; j += blockDim.x) xyzz_add_inl(a, s[j]);

@@ -6,6 +6,7 @@
 
 #include "common.cuh"
 #include "msm.cuh"
+#include "msm_table.cuh"
 
 namespace zg {
 
@@ -157,24 +158,36 @@ int host_group_op(int op, const void* a, const void* b, int form, void* out) {
 // ---------------------------------------------------------------------------------------------
 // Queues the device pipeline on ctx's stream; the W window sums land in ctx->pinned (asynchronous copy).
 // msm_finish() waits for them and runs the host tail.  Several contexts ("lanes") can be in flight at once.
+// `tab` (may be null): d_pts is a fixed-base table of tab->D levels of tab->N points, T_j[i] = 2^(j c) P_i at
+// d_pts[j * N + i], and the MSM runs over the bases [first, first + n) in table mode (msm_table.cuh).  Without it d_pts
+// points at the n bases themselves.
 template <class F, class Fr>
-int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c) {
+int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
+               const MsmTable* tab) {
   ctx->job_n = n;
   if (n == 0) return ZG_OK;
   const Affine<F>* d_bases = reinterpret_cast<const Affine<F>*>(d_pts);
-  const MsmPlan plan = msm_make_plan(n, Fr::Params::BITS, force_c);
+  if (tab && (force_c || n < 1024)) {  // an explicit window width, or too few points to sort by group: the plain form on level 0
+    d_bases += tab->first;
+    tab = nullptr;
+  }
+  const MsmPlan plan = tab ? msm_make_table_plan(n, Fr::Params::BITS, tab->c, tab->D) : msm_make_plan(n, Fr::Params::BITS, force_c);
   const MsmPlan& p = plan;
   ctx->job_W = p.W;
   ctx->job_c = p.c;
-  ZG_TRY(ctx->pinned_reserve((size_t)p.W * sizeof(XYZZ<F>) + 256));
-  if ((uint64_t)p.W * (uint64_t)n >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 32-bit entry positions with headroom
-  const size_t WN = (size_t)p.W * n, WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
+  ctx->job_table_shift = tab ? p.shift : -1;
+  const int rows = tab ? 2 * p.W : p.W;  // window sums; table mode: weighted group sums, then plain group sums
+  ZG_TRY(ctx->pinned_reserve((size_t)rows * sizeof(XYZZ<F>) + 256));
+  const size_t WN = tab ? p.E : (size_t)p.W * n;  // entries
+  if ((uint64_t)WN >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 32-bit entry positions with headroom
+  const size_t WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
   const uint32_t nhi = p.nb >= 512 ? (p.nb >> 8) : 0;  // two-level sort when a window has >= 512 buckets
   size_t need = (nhi ? zg_ctx::ws_round(WN * 4) + zg_ctx::ws_round(WN) + 2 * zg_ctx::ws_round((size_t)p.W * (nhi + 1) * 4) : 0) +
                 zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 5 * zg_ctx::ws_round(WB * 4) + zg_ctx::ws_round((WB + 1) * 4) +
                 zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) + zg_ctx::ws_round(WC * 4) +
                 zg_ctx::ws_round((size_t)p.W * 1024 * 4) +
-                zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)p.W * p.T * sizeof(XYZZ<F>));
+                zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)rows * p.T * sizeof(XYZZ<F>)) +
+                (tab ? zg_ctx::ws_round(WN * 4) + 3 * zg_ctx::ws_round(129 * 4) : 0);
   ZG_TRY(ctx->ws_reserve(need));
   int16_t* dig = ctx->ws_take<int16_t>(WN);
   uint32_t* sorted = ctx->ws_take<uint32_t>(WN);
@@ -189,7 +202,16 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   uint32_t* order = ctx->ws_take<uint32_t>(WC);
   uint32_t* lencur = ctx->ws_take<uint32_t>((size_t)p.W * 1024);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
-  XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)p.W * p.T);
+  XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)rows * p.T);
+  uint32_t *fent = nullptr, *gcnt = nullptr, *gstart = nullptr, *gcursor = nullptr;
+  if (tab) {
+    fent = ctx->ws_take<uint32_t>(WN);
+    gcnt = ctx->ws_take<uint32_t>(129);
+    gstart = ctx->ws_take<uint32_t>(129);
+    gcursor = ctx->ws_take<uint32_t>(129);
+    if (!fent || !gcnt || !gstart || !gcursor) return ZG_ERR_OUT_OF_MEMORY;
+  }
+  uint16_t* fkey = reinterpret_cast<uint16_t*>(dig);  // table mode: bucket-within-group of every entry (same size as dig)
   uint32_t *mid_ent = nullptr, *cursor1 = nullptr, *pstart = nullptr;
   uint8_t* mid_lo = nullptr;
   if (nhi) {
@@ -208,31 +230,67 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   if (!attr_done) {
     ZG_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
     ZG_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
+    ZG_HIP(hipFuncSetAttribute((const void*)k_hist_table, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
+    ZG_HIP(hipFuncSetAttribute((const void*)k_scatter_table, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
     attr_done = true;
   }
   ctx->prof_begin();
   ctx->mark("digits");
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
                      (size_t)(p.W + 1 + 64), heavy);
-  hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
-                     p.c, p.W, p.K, dig, ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr);
-  ctx->mark("hist");
-  hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
+  uint32_t* dense_counters = ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr;
+  if (tab) {
+    // level 0 of the sort: entries by bucket group
+    uint32_t tile_scalars = TABLE_TILE / (uint32_t)p.D;
+    if (tile_scalars > 1024) tile_scalars = 1024;
+    size_t cblocks = (n + 255) / 256;
+    if (cblocks > 2048) cblocks = 2048;
+    ZG_HIP(hipMemsetAsync(gcnt, 0, 129 * 4, st));
+    hipLaunchKernelGGL((k_table_count<Fr>), dim3((unsigned)cblocks), dim3(256), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K,
+                       p.shift, gcnt, dense_counters);
+    hipLaunchKernelGGL(k_table_starts, dim3(1), dim3(64), 0, st, gcnt, (uint32_t)p.W, gstart, gcursor);
+    hipLaunchKernelGGL((k_table_scatter<Fr>), dim3((unsigned)((n + tile_scalars - 1) / tile_scalars)), dim3(1024), 0, st, d_scalars,
+                       n, scalars_mont, p.c, p.D, p.K, p.shift, (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first,
+                       gcursor, fent, fkey);
+    ctx->mark("hist");
+    hipLaunchKernelGGL(k_hist_table, dim3(p.nchunk, p.W), dim3(1024), lds, st, fkey, gstart, p.nb, cnt);
+  } else {
+    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
+                       p.c, p.W, p.K, dig, dense_counters);
+    ctx->mark("hist");
+    hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
+  }
   ctx->mark("scan");
   hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits, nhi,
-                     cursor1, pstart, lencur, ffirst);
+                     cursor1, pstart, lencur, ffirst, gstart);
   ctx->mark("scatter");
   // Window groups (experiment, off unless ZG_MSM_SPLIT is set): the top `g0` windows are sorted first and accumulated at
   // once while the remaining windows are sorted on a second stream.  Measured at 2^24 points: 35.0 ms against 30.4 ms
   // for the plain sequence -- the sort's 1024-lane workgroups displace accumulation waves for longer than the sort
   // takes on its own (k_accum 25.1 -> 31.6 ms), so the sequence stays sort-then-accumulate.
   const uint32_t Wn = (uint32_t)p.W;
-  const bool split = nhi && Wn >= 8 && n >= ((size_t)1 << 21) && getenv("ZG_MSM_SPLIT");
+  const bool split = !tab && nhi && Wn >= 8 && n >= ((size_t)1 << 21) && getenv("ZG_MSM_SPLIT");
   const uint32_t g0 = split ? (Wn + 3) / 4 : Wn;  // windows [Wn - g0, Wn) form the first group
   const uint32_t w_lo = Wn - g0;
   if (split) ZG_TRY(ctx->side_init());
+  const size_t per_group = WN / Wn;  // entries of a window / an average bucket group
   auto scatter_group = [&](hipStream_t s, uint32_t w0, uint32_t cntw) {
-    if (nhi) {
+    if (tab) {
+      if (nhi) {
+        size_t t1 = (2 * per_group + SORT_TILE1 - 1) / SORT_TILE1;
+        if (t1 < 1) t1 = 1;
+        if (t1 > 4096) t1 = 4096;
+        hipLaunchKernelGGL(k_scatter_hi_table, dim3((unsigned)t1, cntw), dim3(1024), 0, s, fent, fkey, gstart, nhi, cursor1, mid_ent,
+                           mid_lo);
+        size_t tiles = (2 * per_group / nhi + SORT_TILE2 - 1) / SORT_TILE2;
+        if (tiles < 1) tiles = 1;
+        if (tiles > 64) tiles = 64;
+        hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, cntw), dim3(1024), 0, s, mid_ent, mid_lo, pstart, nhi, p.nb,
+                           cursor, sorted, w0);
+      } else {
+        hipLaunchKernelGGL(k_scatter_table, dim3(p.nchunk, p.W), dim3(1024), lds, s, fent, fkey, gstart, p.nb, cursor, sorted);
+      }
+    } else if (nhi) {
       hipLaunchKernelGGL(k_scatter_hi, dim3((unsigned)((n + SORT_TILE1 - 1) / SORT_TILE1), cntw), dim3(1024), 0, s, dig, n, nhi,
                          cursor1, mid_ent, mid_lo, w0);
       size_t tiles = (2 * n / nhi + SORT_TILE2 - 1) / SORT_TILE2;
@@ -275,21 +333,21 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     if (chunks > 64) chunks = 64;
     hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 128), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
     hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 128), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
-    if (n / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK)  // more than 2^18 units in one bucket: a third level
+    if (WN / Wn / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK || (tab && WN / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK))  // more than 2^18 units in one bucket: a third level
       hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L,
                          COMBINE_CHUNK * COMBINE_CHUNK, part);
   }
   ctx->mark("reduce1");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
-                     p.k, p.L, (uint32_t)p.W, seg);
+                     p.k, p.L, (uint32_t)p.W, seg, tab ? seg + (size_t)p.W * p.T : (XYZZ<F>*)nullptr);
   ctx->mark("reduce2");
-  hipLaunchKernelGGL((k_reduce2<F>), dim3(p.W), dim3(p.T < 1024 ? p.T : 1024), 0, st, seg, p.T);
+  hipLaunchKernelGGL((k_reduce2<F>), dim3(rows), dim3(p.T < 1024 ? p.T : 1024), 0, st, seg, p.T);
   ctx->mark("end");
   ZG_HIP(hipGetLastError());
   // gather the W window sums (strided by T) with one 2D copy into pinned host memory
-  ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), p.W,
+  ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), rows,
                           hipMemcpyDeviceToHost, st));
-  ZG_HIP(hipMemcpyAsync((char*)ctx->pinned + (size_t)p.W * sizeof(XYZZ<F>), wunits + p.W + 1, 256, hipMemcpyDeviceToHost, st));
+  ZG_HIP(hipMemcpyAsync((char*)ctx->pinned + (size_t)rows * sizeof(XYZZ<F>), wunits + p.W + 1, 256, hipMemcpyDeviceToHost, st));
   return ZG_OK;
 }
 
@@ -302,8 +360,24 @@ int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
   if (ctx->job_n > 0) {
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof_end();
-    acc = host_horner(reinterpret_cast<const XYZZ<F>*>(ctx->pinned), ctx->job_W, ctx->job_c);
-    const uint32_t* dc = reinterpret_cast<const uint32_t*>((const char*)ctx->pinned + (size_t)ctx->job_W * sizeof(XYZZ<F>));
+    const XYZZ<F>* rows = reinterpret_cast<const XYZZ<F>*>(ctx->pinned);
+    int nrows = ctx->job_W;
+    if (ctx->job_table_shift >= 0) {
+      // bucket (group g, key k) weighs g * 2^shift + k + 1: sum_g R_g + 2^shift * sum_g g * S_g  (R weighted, S plain sums)
+      const int W = ctx->job_W;
+      nrows = 2 * W;
+      XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
+      for (int g = W - 1; g >= 1; g--) {
+        xyzz_add(run, rows[W + g]);
+        xyzz_add(tot, run);
+      }
+      for (int i = 0; i < ctx->job_table_shift; i++) tot = xyzz_dbl(tot);
+      for (int g = 0; g < W; g++) xyzz_add(tot, rows[g]);
+      acc = tot;
+    } else {
+      acc = host_horner(rows, ctx->job_W, ctx->job_c);
+    }
+    const uint32_t* dc = reinterpret_cast<const uint32_t*>((const char*)ctx->pinned + (size_t)nrows * sizeof(XYZZ<F>));
     ctx->job_dense = 0;
     for (int i = 0; i < 64; i++) ctx->job_dense += dc[i];
   }
@@ -319,9 +393,40 @@ int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
 
 template <class F, class Fr>
 int msm_run(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t n, int scalars_mont, int force_c,
-            int out_form, void* out_affine_host) {
-  ZG_TRY((msm_launch<F, Fr>(ctx, d_pts, d_scalars, n, scalars_mont, force_c)));
+            int out_form, void* out_affine_host, const MsmTable* tab) {
+  ZG_TRY((msm_launch<F, Fr>(ctx, d_pts, d_scalars, n, scalars_mont, force_c, tab)));
   return msm_finish<F>(ctx, out_form, out_affine_host);
+}
+
+// digit width (0: chosen from N) and level count of a fixed-base table over N bases
+template <class Fr>
+int table_params(size_t N, int window_bits, int* c, int* D) {
+  if (window_bits != 0 && (window_bits < MSM_TABLE_MIN_C || window_bits > MSM_TABLE_MAX_C)) return ZG_ERR_INVALID_ARGUMENT;
+  *c = window_bits ? window_bits : msm_table_pick_c(N);
+  *D = msm_table_digits(Fr::Params::BITS, *c);
+  return ZG_OK;
+}
+
+// Levels 1 .. D-1 of a fixed-base table from level 0 (d_table[0 .. N)): T_j = 2^c T_{j-1}, normalised to affine
+template <class F>
+int table_build(zg_ctx* ctx, void* d_table, size_t N, int c, int D) {
+  if (N == 0) return ZG_OK;
+  size_t need = zg_ctx::ws_round(N * sizeof(XYZZ<F>)) + zg_ctx::ws_round(N * sizeof(F));
+  ZG_TRY(ctx->ws_reserve(need));
+  XYZZ<F>* tmp = ctx->ws_take<XYZZ<F>>(N);
+  F* pref = ctx->ws_take<F>(N);
+  if (!tmp || !pref) return ZG_ERR_OUT_OF_MEMORY;
+  Affine<F>* t = reinterpret_cast<Affine<F>*>(d_table);
+  const size_t lanes = (N + GEN_CHUNK - 1) / GEN_CHUNK;
+  for (int j = 1; j < D; j++) {
+    hipLaunchKernelGGL((k_table_next<F>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, t + (size_t)(j - 1) * N, N, c,
+                       tmp);
+    hipLaunchKernelGGL((k_normalize<F>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->stream, tmp, pref, N,
+                       t + (size_t)j * N);
+  }
+  ZG_HIP(hipGetLastError());
+  ZG_HIP(hipStreamSynchronize(ctx->stream));
+  return ZG_OK;
 }
 
 template <class F>
@@ -481,6 +586,8 @@ struct G2Gen {
                                 &zg::group_fft<F, FR>,                                            \
                                 &zg::group_scale<F, FR>,                                          \
                                 &zg::group_combine<F, FR>,                                        \
-                                &zg::host_group_sum<F>};                                          \
+                                &zg::host_group_sum<F>,                                           \
+                                &zg::table_build<F>,                                              \
+                                &zg::table_params<FR>};                                           \
     return &ops;                                                                                  \
   }

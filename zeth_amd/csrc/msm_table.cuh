@@ -1,0 +1,213 @@
+// Fixed-base table mode of the MSM: the bases of a proving key never change, and 288 GB of HBM hold D = ceil(bits / c)
+// precomputed multiples T_j[i] = 2^(j c) P_i of every base.  Then sum_i s_i P_i = sum_i sum_j d_ij T_j[i] with the signed
+// c-bit digits d_ij of s_i, and ALL n * D terms fall into one set of 2^(c-1) buckets: the bucket reduction is paid once
+// instead of once per window, so c can grow to 22 (12 digits per 254-bit scalar where the windowed form needs 16
+// or 17) -- a quarter fewer mixed additions in the dominant kernel for 12x the base memory.
+//
+// Sorting n * D (entry, bucket) pairs on 21 bucket bits is a three-level most-significant-digit-first counting sort:
+//   k_table_count / k_table_starts / k_table_scatter   by bucket group (the top bits: <= 128 groups of 2^15 buckets)
+//   k_scatter_hi_table, k_scatter_lo                    inside a group, as the windowed form sorts a window (msm.cuh)
+// Every level bins a tile in LDS and copies it out in runs, so global stores stay line-sized.
+#pragma once
+#include "msm.cuh"
+
+namespace zg {
+
+static constexpr uint32_t TABLE_TILE = 8192;  // entries per tile of the group-level pass (tile scalars = TABLE_TILE / D)
+
+// entries per bucket group and (optionally) the number of scalars other than 0 and 1
+template <class Fr>
+__global__ void __launch_bounds__(256) k_table_count(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int D,
+                                                      AddConst K, int shift, uint32_t* __restrict__ gcnt /* [W] */,
+                                                      uint32_t* __restrict__ dense_count) {
+  __shared__ uint32_t h[128], nd;
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
+  if (threadIdx.x == 0) nd = 0;
+  __syncthreads();
+  uint32_t my_dense = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    bool dense;
+    recode_scalar<Fr>(scalars, i, mont, c, D, K, &dense, [&](int, int d) {
+      if (d != 0) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1) >> shift], 1u);
+    });
+    my_dense += dense ? 1u : 0u;
+  }
+  if (dense_count && my_dense) atomicAdd(&nd, my_dense);
+  __syncthreads();
+  if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&gcnt[threadIdx.x], h[threadIdx.x]);
+  if (dense_count && threadIdx.x == 0 && nd) atomicAdd(dense_count + (blockIdx.x & 63u), nd);
+}
+
+static __global__ void __launch_bounds__(64) k_table_starts(const uint32_t* __restrict__ gcnt, uint32_t W,
+                                                            uint32_t* __restrict__ gstart /* [W + 1] */,
+                                                            uint32_t* __restrict__ gcursor /* [W] */) {
+  if (threadIdx.x != 0) return;
+  uint32_t run = 0;
+  for (uint32_t w = 0; w < W; w++) {
+    gstart[w] = run;
+    gcursor[w] = run;
+    run += gcnt[w];
+  }
+  gstart[W] = run;
+}
+
+// One tile of scalars per workgroup, one scalar per lane: bin the tile's entries by bucket group in LDS, claim a run
+// per group, copy out.  Entry = (j * N + first + i) | sign << 31 (index into the table), key = bucket within the group.
+template <class Fr>
+__global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int D,
+                                                         AddConst K, int shift, uint32_t W, uint32_t tile_scalars,
+                                                         uint32_t table_n, uint32_t first, uint32_t* __restrict__ gcursor,
+                                                         uint32_t* __restrict__ fent, uint16_t* __restrict__ fkey) {
+  __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
+  __shared__ uint32_t buf_ent[TABLE_TILE];
+  __shared__ uint16_t buf_key[TABLE_TILE];
+  __shared__ uint8_t buf_bin[TABLE_TILE];
+  const size_t i = (size_t)blockIdx.x * tile_scalars + threadIdx.x;
+  const bool live = threadIdx.x < tile_scalars && i < n;
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
+  __syncthreads();
+  bool dense;
+  if (live)
+    recode_scalar<Fr>(scalars, i, mont, c, D, K, &dense, [&](int, int d) {
+      if (d != 0) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1) >> shift], 1u);
+    });
+  __syncthreads();
+  uint32_t v = 0, incl = 0;
+  if (threadIdx.x < 128) {
+    v = threadIdx.x < W ? h[threadIdx.x] : 0;
+    incl = wave_inclusive_scan(v);
+    if (threadIdx.x == 63) wsum = incl;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
+    lstart[threadIdx.x] = excl;
+    gbase[threadIdx.x] = v ? atomicAdd(&gcursor[threadIdx.x], v) : 0;
+    h[threadIdx.x] = excl;
+  }
+  __syncthreads();
+  const uint32_t key_mask = (1u << shift) - 1u;
+  if (live)
+    recode_scalar<Fr>(scalars, i, mont, c, D, K, &dense, [&](int j, int d) {
+      if (d != 0) {
+        const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
+        const uint32_t pos = atomicAdd(&h[b >> shift], 1u);
+        buf_ent[pos] = ((uint32_t)j * table_n + first + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
+        buf_key[pos] = (uint16_t)(b & key_mask);
+        buf_bin[pos] = (uint8_t)(b >> shift);
+      }
+    });
+  __syncthreads();
+  const uint32_t total = h[W - 1];  // the last group's running cursor ends at the tile's entry count
+  for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+    const uint32_t bin = buf_bin[q];
+    const uint32_t g = gbase[bin] + (q - lstart[bin]);
+    fent[g] = buf_ent[q];
+    fkey[g] = buf_key[q];
+  }
+}
+
+// bucket counts of a group from its key list (k_hist's counterpart); grid (chunks, W)
+static __global__ void __launch_bounds__(1024) k_hist_table(const uint16_t* __restrict__ fkey, const uint32_t* __restrict__ gstart,
+                                                            uint32_t nb, uint32_t* __restrict__ cnt) {
+  extern __shared__ uint32_t lh[];
+  const uint32_t w = blockIdx.y;
+  const uint32_t start = gstart[w], end = gstart[w + 1];
+  if (start == end) return;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  const uint32_t per = (end - start + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = start + blockIdx.x * per < end ? start + blockIdx.x * per : end;
+  const uint32_t hi = lo + per < end ? lo + per : end;
+  for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&lh[fkey[q]], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    const uint32_t v = lh[b];
+    if (v) atomicAdd(&cnt[(size_t)w * nb + b], v);
+  }
+}
+
+// single-level finish for groups of fewer than 512 buckets (small tables): k_scatter's counterpart; grid (chunks, W)
+static __global__ void __launch_bounds__(1024) k_scatter_table(const uint32_t* __restrict__ fent, const uint16_t* __restrict__ fkey,
+                                                               const uint32_t* __restrict__ gstart, uint32_t nb,
+                                                               uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lh[];
+  const uint32_t w = blockIdx.y;
+  const uint32_t start = gstart[w], end = gstart[w + 1];
+  if (start == end) return;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  const uint32_t per = (end - start + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = start + blockIdx.x * per < end ? start + blockIdx.x * per : end;
+  const uint32_t hi = lo + per < end ? lo + per : end;
+  for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&lh[fkey[q]], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    const uint32_t v = lh[b];
+    if (v) lh[b] = atomicAdd(&cursor[(size_t)w * nb + b], v);
+  }
+  __syncthreads();
+  for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) sorted[atomicAdd(&lh[fkey[q]], 1u)] = fent[q];
+}
+
+// k_scatter_hi's counterpart: tiles of a group's (entry, key) list split over the group's partitions of 256 buckets;
+// grid (tile slots, W), tiles taken grid-stride so that a group holding most entries is still covered
+static __global__ void __launch_bounds__(1024) k_scatter_hi_table(const uint32_t* __restrict__ fent, const uint16_t* __restrict__ fkey,
+                                                                  const uint32_t* __restrict__ gstart, uint32_t nhi,
+                                                                  uint32_t* __restrict__ cursor1, uint32_t* __restrict__ mid_ent,
+                                                                  uint8_t* __restrict__ mid_lo) {
+  __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
+  __shared__ uint32_t buf_ent[SORT_TILE1];
+  __shared__ uint8_t buf_lo[SORT_TILE1], buf_bin[SORT_TILE1];
+  const uint32_t w = blockIdx.y;
+  const uint32_t start = gstart[w], end = gstart[w + 1];
+  for (uint32_t lo = start + blockIdx.x * SORT_TILE1; lo < end; lo += gridDim.x * SORT_TILE1) {
+    const uint32_t hi = lo + SORT_TILE1 < end ? lo + SORT_TILE1 : end;
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&h[fkey[q] >> 8], 1u);
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (threadIdx.x < 128) {
+      v = threadIdx.x < nhi ? h[threadIdx.x] : 0;
+      incl = wave_inclusive_scan(v);
+      if (threadIdx.x == 63) wsum = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
+      lstart[threadIdx.x] = excl;
+      gbase[threadIdx.x] = v ? atomicAdd(&cursor1[(size_t)w * nhi + threadIdx.x], v) : 0;
+      h[threadIdx.x] = excl;
+    }
+    __syncthreads();
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
+      const uint32_t b = fkey[q];
+      const uint32_t pos = atomicAdd(&h[b >> 8], 1u);
+      buf_ent[pos] = fent[q];
+      buf_lo[pos] = (uint8_t)(b & 255u);
+      buf_bin[pos] = (uint8_t)(b >> 8);
+    }
+    __syncthreads();
+    const uint32_t total = hi - lo;
+    for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+      const uint32_t bin = buf_bin[q];
+      const uint32_t g = gbase[bin] + (q - lstart[bin]);
+      mid_ent[g] = buf_ent[q];
+      mid_lo[g] = buf_lo[q];
+    }
+    __syncthreads();
+  }
+}
+
+// next level of the table: out[i] = 2^c * prev[i] (XYZZ; normalised to affine by k_normalize afterwards)
+template <class F>
+__global__ void __launch_bounds__(256) k_table_next(const Affine<F>* __restrict__ prev, size_t n, int c, XYZZ<F>* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<F> p = XYZZ<F>::from_affine(prev[i]);
+  for (int k = 0; k < c; k++) p = xyzz_dbl(p);
+  out[i] = p;
+}
+
+}  // namespace zg

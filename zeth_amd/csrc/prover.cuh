@@ -317,12 +317,12 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(qap_h());
     static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
     static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
-    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c));
+    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, nullptr));
     auto width = [](uint32_t dense) { return lane_c ? lane_c : dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
-    ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0])));
-    ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1])));
-    ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2])));
-    ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3])));
+    ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0]), nullptr));
+    ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1]), nullptr));
+    ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2]), nullptr));
+    ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3]), nullptr));
     stamp("all work queued");
     // Host tail, ordered so that everything that does not need a device result runs while the GPU is busy:
     // the four blinding multiples of delta first, then each evaluation as its lane completes.

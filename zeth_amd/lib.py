@@ -74,6 +74,8 @@ def load_library():
     L.zg_bases_batch_exp.argtypes = [vp, ci, ci, vp, sz, ctypes.POINTER(vp)]
     L.zg_bases_count.argtypes = [vp, ctypes.POINTER(sz)]
     L.zg_bases_read.argtypes = [vp, sz, sz, ci, vp]
+    L.zg_bases_precompute.argtypes = [vp, ci]
+    L.zg_bases_table_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.zg_bases_free.argtypes = [vp]
     L.zg_bases_free.restype = None
     L.zg_msm.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp]
@@ -256,6 +258,18 @@ class Bases:
         h = ctypes.c_void_p()
         _check(ctx._L.zg_bases_batch_exp(ctx._h, curve, group, bytes(buf), n, ctypes.byref(h)))
         return cls(ctx, curve, group, h, n)
+
+    def precompute(self, window_bits: int = 0) -> "Bases":
+        """Fixed-base table (zg_bases_precompute): the multiples 2^(j c) P_i stay in HBM and every later msm() sorts
+        all digits into one bucket set.  Returns self."""
+        _check(self._L.zg_bases_precompute(self._h, window_bits))
+        return self
+
+    def table_info(self) -> Tuple[int, int]:
+        """(digit width c, levels D); (0, 0) without a table."""
+        c, d = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._L.zg_bases_table_info(self._h, ctypes.byref(c), ctypes.byref(d)))
+        return c.value, d.value
 
     def read_bytes(self, first: int, count: int, form: int = FORM_PLAIN) -> bytes:
         ab = affine_bytes(self.curve, self.group)
