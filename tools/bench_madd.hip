@@ -176,7 +176,7 @@ static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbase
   float best = 1e9f;
   for (int r = 0; r < 3; r++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_accum<F>), dim3(blocks + extra_blocks, 1), dim3(256), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu, 1u);
+    hipLaunchKernelGGL((k_accum<F>), dim3(blocks + extra_blocks, 1), dim3(256), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu, 1u, 0u);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -25,6 +25,9 @@ if [ "$1" = "1" ]; then
     echo part1 done
 elif [ "$1" = "2" ]; then
     timeout -k 10 200 python tools/bench_sweep.py g1 > "$O/msm_g1_sweep.jsonl" 2> "$O/sweep.err" &&
+    timeout -k 10 200 python tools/bench_sweep.py g1t 0 > "$O/msm_g1_table_sweep.jsonl" 2>> "$O/sweep.err" &&
+    timeout -k 10 200 python tools/bench_sweep.py othert > "$O/msm_g2_bls_table.jsonl" 2>> "$O/sweep.err" &&
+    timeout -k 10 100 python bench.py --no-table --no-prove --no-cpu-baseline > "$O/bench_windowed.json" 2>> "$O/sweep.err" &&
     timeout -k 10 200 python tools/bench_sweep.py other > "$O/msm_g2_bls.jsonl" 2>> "$O/sweep.err" &&
     timeout -k 10 100 python tools/bench_sweep.py ntt > "$O/ntt.jsonl" 2>> "$O/sweep.err" &&
     timeout -k 10 200 python tools/bench_prove.py --in-flight 4 > "$O/prove_joinsplit_shaped.json" 2> "$O/prove.err" &&

@@ -1,5 +1,5 @@
 """HBM bytes per launch from two rocprofv3 counter passes (rocpd sqlite):
-    python tools/pmc_summary.py FETCH_DB WRITE_DB [CALIB_DB] > profiles/rN_pmc_hbm_traffic.json
+    python tools/pmc_summary.py FETCH_DB WRITE_DB [CALIB_DB [DIGITS]] > profiles/rN_pmc_hbm_traffic.json
 FETCH_SIZE / WRITE_SIZE are reported in KB.  The calibration database (tools/calib_gather.hip under --pmc FETCH_SIZE)
 says how FETCH_SIZE relates to bytes for the two access patterns here: exact for random 64-byte gathers, one half for
 wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section)."""
@@ -8,7 +8,8 @@ import re
 import sqlite3
 import sys
 
-N, WINDOWS, POINT_BYTES = 1 << 24, 17, 64  # k_accum's algorithmic bytes: one affine point per window entry
+N, ENTRY_BYTES = 1 << 24, 68  # k_accum's algorithmic bytes per (point, digit): a 64 B affine base + a 4 B sorted entry
+DIGITS = int(sys.argv[4]) if len(sys.argv) > 4 else 16  # digits per scalar: 16 windowed, 12 with the fixed-base table
 
 
 def per_kernel(path, counter):
@@ -49,7 +50,8 @@ for k in sorted(set(fetch) | set(write)):
     res["kernels"][k] = e
 acc = res["kernels"].get("k_accum")
 if acc:
-    alg = N * WINDOWS * POINT_BYTES
+    alg = N * DIGITS * ENTRY_BYTES
+    acc["digits_per_scalar"] = DIGITS
     acc["algorithmic_bytes_per_launch"] = alg
     acc["traffic_over_algorithmic"] = (acc["FETCH_SIZE_bytes_per_launch"] + acc.get("WRITE_SIZE_bytes_per_launch", 0)) / alg
 print(json.dumps(res, indent=1))

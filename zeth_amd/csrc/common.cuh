@@ -51,7 +51,7 @@ struct zg_ctx {
   size_t pinned_cap = 0;
   size_t job_n = 0;
   int job_W = 0, job_c = 0;
-  int job_table_shift = -1;  // >= 0: the job ran in fixed-base table mode with 2^shift buckets per group
+  int job_table_gbits = -1;  // >= 0: the job ran in fixed-base table mode with 2^gbits bucket groups
   bool want_dense = false;  // count scalars other than 0/1 during recoding (prover lanes)
   uint32_t job_dense = 0;  // scalars other than 0/1 seen by the last MSM on this context
   int pinned_reserve(size_t bytes) {

@@ -30,9 +30,11 @@ static constexpr int MSM_MAX_C = 16;
 static constexpr uint32_t COMBINE_SERIAL_MAX = 8;  // units folded serially by the first unit's lane; more: tree (k_combine_tree)
 static constexpr uint32_t COMBINE_CHUNK = 512;     // units per workgroup and launch of the tree
 // Units are handed to the accumulation kernel longest first, by length class: class UNIT_CLASSES = full-length units,
-// classes 0..127 = partial units by len * 128 / L (lengths within a class differ by < L / 128, under 1 % of a wave's run)
-static constexpr uint32_t UNIT_CLASSES = 128;
-static constexpr uint32_t UNIT_CLASS_STRIDE = 256;
+// classes 0..1023 = partial units by (len - 1) * 1024 / L -- one class per length, since L <= 1024: the lanes of a wave
+// run in lockstep to the longest unit among them, and classes a few entries wide cost the accumulation ~10 % at 2^24
+// points (measured: 21.8 ms with classes 6 entries wide against 19.2 ms with exact lengths, same entries).
+static constexpr uint32_t UNIT_CLASSES = 1024;
+static constexpr uint32_t UNIT_CLASS_STRIDE = 1280;
 __host__ __device__ inline uint32_t unit_class(uint32_t len, uint32_t L) { return ((len - 1) * UNIT_CLASSES) / L; }
 static constexpr int MSM_MAX_W = 48;
 
@@ -59,7 +61,7 @@ struct MsmPlan {
   // fixed-base table mode (msm_make_table_plan): c = digit width (up to 22), D = digits per scalar, all digits share ONE
   // set of 2^(c-1) buckets, cut into W "bucket groups" of nb <= 2^15 buckets that the sort, the unit table, the
   // accumulation and the reduction treat the way they treat the windows of the plain mode; E = n * D entries
-  int table, D, shift;
+  int table, D, shift /* log2 nb */, gbits /* log2 W */;
   size_t E;
 };
 
@@ -73,14 +75,13 @@ inline int ilog2_floor(size_t n) {
 inline int msm_table_digits(int scalar_bits, int c) { return (scalar_bits + 2 + c - 1) / c; }
 static constexpr int MSM_TABLE_MIN_C = 10, MSM_TABLE_MAX_C = 22;
 
-// digit width of the table for N fixed bases: about log2(N) - 1 (accumulation n * D mixed additions against a
-// reduction of 2^c additions), at most 22 (128 bucket groups of 2^15 would be the next step: not worth 1/12 fewer digits)
+// Digit width of the table for N fixed bases, measured on MI355X (BN254 G1, tools/bench_sweep.py g1t): 22 from 2^23
+// bases (12 digits, 2^21 buckets), 20 from 2^21 (13 digits), 17 below (16 digits, where the table saves no additions and
+// only the per-window reductions).  Widths whose top digit is nearly empty are avoided: at c = 21 the 13th digit has
+// 2 bits, four buckets take a quarter of all scalars each, and the accumulation runs 60 % longer than at c = 20.
 inline int msm_table_pick_c(size_t N) {
   int lg = ilog2_floor(N ? N : 1) + ((N & (N - 1)) ? 1 : 0);
-  int c = lg - 1;
-  if (c < 12) c = 12;
-  if (c > MSM_TABLE_MAX_C) c = MSM_TABLE_MAX_C;
-  return c;
+  return lg >= 23 ? 22 : lg >= 21 ? 20 : 17;
 }
 
 // window width for n scalars that are not 0 or 1, tuned on MI355X (tools/tune_c.py): odd widths keep the
@@ -150,8 +151,11 @@ inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
   const int bucket_bits = c - 1;
   p.shift = bucket_bits < 15 ? bucket_bits : 15;
   p.nb = 1u << p.shift;
-  p.W = 1 << (bucket_bits - p.shift);
+  p.gbits = bucket_bits - p.shift;
+  p.W = 1 << p.gbits;
   size_t L = p.E >> 18;
+  const size_t load2 = 2 * (p.E >> bucket_bits);  // twice the mean bucket load: an ordinary bucket stays one unit
+  if (L < load2) L = load2;
   if (L < 32) L = 32;
   if (L > 1024) L = 1024;
   if (const char* e = getenv("ZG_MSM_UNIT_LEN")) {
@@ -341,7 +345,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
   const uint32_t lo = wv * per_wave < nb ? wv * per_wave : nb;
   const uint32_t hi = lo + per_wave < nb ? lo + per_wave : nb;
   const uint32_t* __restrict__ c = cnt + (size_t)w * nb;
-  if (tid <= UNIT_CLASSES) lh[tid] = 0;
+  for (uint32_t q = tid; q <= UNIT_CLASSES; q += blockDim.x) lh[q] = 0;
   __syncthreads();
   // pass 1: per-wave totals, histogram of unit length classes (v / L full units and one partial unit of v % L)
   uint32_t sa = 0, sb = 0, sc = 0, mx = 0;
@@ -371,10 +375,10 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
   }
   __syncthreads();
   // slot ranges of the length classes, longest first (full-length units, then the partial classes from longest to shortest)
-  if (tid <= UNIT_CLASSES) {
+  for (uint32_t cls = tid; cls <= UNIT_CLASSES; cls += blockDim.x) {
     uint32_t before = 0;
-    for (uint32_t q = tid + 1; q <= UNIT_CLASSES; q++) before += lh[q];
-    lencur[(size_t)w * UNIT_CLASS_STRIDE + tid] = before;
+    for (uint32_t q = cls + 1; q <= UNIT_CLASSES; q++) before += lh[q];
+    lencur[(size_t)w * UNIT_CLASS_STRIDE + cls] = before;
   }
   // pass 2: exclusive prefixes
   uint32_t ea = 0, eb = 0, ef = 0, ta = 0, tb = 0;
@@ -593,7 +597,7 @@ static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict
   const uint32_t w = in_range ? (uint32_t)(g / nb) : 0;
   const uint32_t full = v / L, rem = v % L;
   const uint32_t u0 = v ? ufirst[g] : 0, start = v ? boff[g] : 0, fr = v ? ffirst[g] : 0;
-  if (threadIdx.x < UNIT_CLASSES) lc[threadIdx.x] = 0;
+  for (uint32_t q = threadIdx.x; q < UNIT_CLASSES; q += blockDim.x) lc[q] = 0;
   __syncthreads();
   if (v) {
     if (full + (rem ? 1 : 0) > COMBINE_SERIAL_MAX) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)g;
@@ -606,10 +610,12 @@ static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict
   uint32_t rank = 0;
   if (partial && one_window) rank = atomicAdd(&lc[cls], 1u);
   __syncthreads();
-  if (one_window && threadIdx.x < UNIT_CLASSES) {
-    const uint32_t c = lc[threadIdx.x];
+  if (one_window) {
     const uint32_t wb = (uint32_t)(((size_t)blockIdx.x * blockDim.x) / nb);
-    gb[threadIdx.x] = c ? atomicAdd(&lencur[(size_t)wb * UNIT_CLASS_STRIDE + threadIdx.x], c) : 0;
+    for (uint32_t q = threadIdx.x; q < UNIT_CLASSES; q += blockDim.x) {
+      const uint32_t c = lc[q];
+      if (c) gb[q] = atomicAdd(&lencur[(size_t)wb * UNIT_CLASS_STRIDE + q], c);
+    }
   }
   __syncthreads();
   if (partial) {
@@ -696,11 +702,14 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
                                                 const uint32_t* __restrict__ sorted,
                                                 const Affine<F>* __restrict__ bases, XYZZ<F>* __restrict__ part,
                                                 const uint32_t idx_mask /* 0x7FFFFFFF: strips the sign bit */,
-                                                const uint32_t w_end /* windows [w_end - gridDim.y, w_end) */) {
+                                                const uint32_t w_end /* windows [w_end - gridDim.y, w_end) */,
+                                                const uint32_t groups_fastest /* table mode: grid (groups, slot blocks) */) {
   // Workgroups are dispatched in blockIdx order.  The top window comes first: its digits cover fewer values (the scalar's
   // leading bits), so its buckets -- and units -- are the longest, and a long unit that starts late is the kernel's tail.
-  const uint32_t w = w_end - 1 - blockIdx.y;
-  const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
+  // Table mode (groups_fastest): the groups are statistically alike, each with its share of the long units of the
+  // scalars' top digit, so the grid is (group, slot block) and every group's longest units are dispatched first.
+  const uint32_t w = groups_fastest ? blockIdx.x : w_end - 1 - blockIdx.y;
+  const uint32_t ul = (groups_fastest ? blockIdx.y : blockIdx.x) * blockDim.x + threadIdx.x;
   if (ul >= wunits[w]) return;
   const size_t u = order[(size_t)w * cap + ul];  // longest units first; the lanes of a wave get (nearly) equal lengths
   const UnitDesc d = units[u];

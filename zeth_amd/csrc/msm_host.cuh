@@ -175,7 +175,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   const MsmPlan& p = plan;
   ctx->job_W = p.W;
   ctx->job_c = p.c;
-  ctx->job_table_shift = tab ? p.shift : -1;
+  ctx->job_table_gbits = tab ? p.gbits : -1;
   const int rows = tab ? 2 * p.W : p.W;  // window sums; table mode: weighted group sums, then plain group sums
   ZG_TRY(ctx->pinned_reserve((size_t)rows * sizeof(XYZZ<F>) + 256));
   const size_t WN = tab ? p.E : (size_t)p.W * n;  // entries
@@ -185,7 +185,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   size_t need = (nhi ? zg_ctx::ws_round(WN * 4) + zg_ctx::ws_round(WN) + 2 * zg_ctx::ws_round((size_t)p.W * (nhi + 1) * 4) : 0) +
                 zg_ctx::ws_round(WN * 2) + zg_ctx::ws_round(WN * 4) + 5 * zg_ctx::ws_round(WB * 4) + zg_ctx::ws_round((WB + 1) * 4) +
                 zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) + zg_ctx::ws_round(WC * 4) +
-                zg_ctx::ws_round((size_t)p.W * 1024 * 4) +
+                zg_ctx::ws_round((size_t)p.W * UNIT_CLASS_STRIDE * 4) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)rows * p.T * sizeof(XYZZ<F>)) +
                 (tab ? zg_ctx::ws_round(WN * 4) + 3 * zg_ctx::ws_round(129 * 4) : 0);
   ZG_TRY(ctx->ws_reserve(need));
@@ -200,7 +200,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   uint32_t* wunits = ctx->ws_take<uint32_t>(p.W + 1 + 64);  // [W] unit totals, [W] max units per bucket, then 64 dense-scalar counters
   UnitDesc* units = ctx->ws_take<UnitDesc>(WC);
   uint32_t* order = ctx->ws_take<uint32_t>(WC);
-  uint32_t* lencur = ctx->ws_take<uint32_t>((size_t)p.W * 1024);
+  uint32_t* lencur = ctx->ws_take<uint32_t>((size_t)p.W * UNIT_CLASS_STRIDE);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
   XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)rows * p.T);
   uint32_t *fent = nullptr, *gcnt = nullptr, *gstart = nullptr, *gcursor = nullptr;
@@ -247,10 +247,10 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     if (cblocks > 2048) cblocks = 2048;
     ZG_HIP(hipMemsetAsync(gcnt, 0, 129 * 4, st));
     hipLaunchKernelGGL((k_table_count<Fr>), dim3((unsigned)cblocks), dim3(256), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K,
-                       p.shift, gcnt, dense_counters);
+                       (uint32_t)p.W - 1u, gcnt, dense_counters);
     hipLaunchKernelGGL(k_table_starts, dim3(1), dim3(64), 0, st, gcnt, (uint32_t)p.W, gstart, gcursor);
     hipLaunchKernelGGL((k_table_scatter<Fr>), dim3((unsigned)((n + tile_scalars - 1) / tile_scalars)), dim3(1024), 0, st, d_scalars,
-                       n, scalars_mont, p.c, p.D, p.K, p.shift, (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first,
+                       n, scalars_mont, p.c, p.D, p.K, p.gbits, (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first,
                        gcursor, fent, fkey);
     ctx->mark("hist");
     hipLaunchKernelGGL(k_hist_table, dim3(p.nchunk, p.W), dim3(1024), lds, st, fkey, gstart, p.nb, cnt);
@@ -318,12 +318,13 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                      order, heavy);
   ctx->mark("accum");
   const dim3 ablk(ZG_ACCUM_BLOCK);
-  hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + ZG_ACCUM_BLOCK - 1) / ZG_ACCUM_BLOCK, g0), ablk, 0, st, units, wunits, p.cap, order,
-                     sorted, d_bases, part, zg_debug_base_mask(), Wn);
+  const uint32_t ablocks = (p.cap + ZG_ACCUM_BLOCK - 1) / ZG_ACCUM_BLOCK;
+  hipLaunchKernelGGL((k_accum<F>), tab ? dim3(g0, ablocks) : dim3(ablocks, g0), ablk, 0, st, units, wunits, p.cap, order, sorted,
+                     d_bases, part, zg_debug_base_mask(), Wn, tab ? 1u : 0u);
   if (split) {
     ZG_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
     hipLaunchKernelGGL((k_accum<F>), dim3((p.cap + ZG_ACCUM_BLOCK - 1) / ZG_ACCUM_BLOCK, w_lo), ablk, 0, st, units, wunits, p.cap,
-                       order, sorted, d_bases, part, zg_debug_base_mask(), w_lo);
+                       order, sorted, d_bases, part, zg_debug_base_mask(), w_lo, 0u);
   }
   ctx->mark("combine");
   hipLaunchKernelGGL((k_combine_light<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
@@ -362,18 +363,22 @@ int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
     ctx->prof_end();
     const XYZZ<F>* rows = reinterpret_cast<const XYZZ<F>*>(ctx->pinned);
     int nrows = ctx->job_W;
-    if (ctx->job_table_shift >= 0) {
-      // bucket (group g, key k) weighs g * 2^shift + k + 1: sum_g R_g + 2^shift * sum_g g * S_g  (R weighted, S plain sums)
+    if (ctx->job_table_gbits >= 0) {
+      // bucket (group g, key k) weighs k * W + g + 1; rows: R_g = sum_k (k + 1) B_gk, then S_g = sum_k B_gk:
+      //   sum = W * (sum_g R_g - sum_g S_g) + sum_g (g + 1) S_g
       const int W = ctx->job_W;
       nrows = 2 * W;
-      XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
-      for (int g = W - 1; g >= 1; g--) {
+      XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf(), a = XYZZ<F>::inf();
+      for (int g = W - 1; g >= 0; g--) {
         xyzz_add(run, rows[W + g]);
         xyzz_add(tot, run);
+        xyzz_add(a, rows[g]);
       }
-      for (int i = 0; i < ctx->job_table_shift; i++) tot = xyzz_dbl(tot);
-      for (int g = 0; g < W; g++) xyzz_add(tot, rows[g]);
-      acc = tot;
+      run.y = F::neg(run.y);  // run = sum_g S_g
+      xyzz_add(a, run);
+      for (int i = 0; i < ctx->job_table_gbits; i++) a = xyzz_dbl(a);
+      xyzz_add(a, tot);
+      acc = a;
     } else {
       acc = host_horner(rows, ctx->job_W, ctx->job_c);
     }

@@ -4,8 +4,10 @@
 // instead of once per window, so c can grow to 22 (12 digits per 254-bit scalar where the windowed form needs 16
 // or 17) -- a quarter fewer mixed additions in the dominant kernel for 12x the base memory.
 //
-// Sorting n * D (entry, bucket) pairs on 21 bucket bits is a three-level most-significant-digit-first counting sort:
-//   k_table_count / k_table_starts / k_table_scatter   by bucket group (the top bits: <= 128 groups of 2^15 buckets)
+// Sorting n * D (entry, bucket) pairs on 21 bucket bits is a three-level counting sort.  Bucket b (weight b + 1) belongs
+// to group b mod W under key b / W: the top digit of a scalar takes few values (12 bits at c = 22), so the lowest buckets
+// hold n / 4096 entries each on top of their share -- the low bits spread them evenly over the groups.
+//   k_table_count / k_table_starts / k_table_scatter   by bucket group (<= 128 groups of 2^15 buckets)
 //   k_scatter_hi_table, k_scatter_lo                    inside a group, as the windowed form sorts a window (msm.cuh)
 // Every level bins a tile in LDS and copies it out in runs, so global stores stay line-sized.
 #pragma once
@@ -18,7 +20,7 @@ static constexpr uint32_t TABLE_TILE = 8192;  // entries per tile of the group-l
 // entries per bucket group and (optionally) the number of scalars other than 0 and 1
 template <class Fr>
 __global__ void __launch_bounds__(256) k_table_count(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int D,
-                                                      AddConst K, int shift, uint32_t* __restrict__ gcnt /* [W] */,
+                                                      AddConst K, uint32_t gmask /* W - 1 */, uint32_t* __restrict__ gcnt /* [W] */,
                                                       uint32_t* __restrict__ dense_count) {
   __shared__ uint32_t h[128], nd;
   if (threadIdx.x < 128) h[threadIdx.x] = 0;
@@ -28,7 +30,7 @@ __global__ void __launch_bounds__(256) k_table_count(const uint32_t* __restrict_
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     bool dense;
     recode_scalar<Fr>(scalars, i, mont, c, D, K, &dense, [&](int, int d) {
-      if (d != 0) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1) >> shift], 1u);
+      if (d != 0) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1) & gmask], 1u);
     });
     my_dense += dense ? 1u : 0u;
   }
@@ -55,7 +57,7 @@ static __global__ void __launch_bounds__(64) k_table_starts(const uint32_t* __re
 // per group, copy out.  Entry = (j * N + first + i) | sign << 31 (index into the table), key = bucket within the group.
 template <class Fr>
 __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int D,
-                                                         AddConst K, int shift, uint32_t W, uint32_t tile_scalars,
+                                                         AddConst K, int gbits, uint32_t W, uint32_t tile_scalars,
                                                          uint32_t table_n, uint32_t first, uint32_t* __restrict__ gcursor,
                                                          uint32_t* __restrict__ fent, uint16_t* __restrict__ fkey) {
   __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
@@ -64,12 +66,13 @@ __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restri
   __shared__ uint8_t buf_bin[TABLE_TILE];
   const size_t i = (size_t)blockIdx.x * tile_scalars + threadIdx.x;
   const bool live = threadIdx.x < tile_scalars && i < n;
+  const uint32_t gmask = W - 1u;
   if (threadIdx.x < 128) h[threadIdx.x] = 0;
   __syncthreads();
   bool dense;
   if (live)
     recode_scalar<Fr>(scalars, i, mont, c, D, K, &dense, [&](int, int d) {
-      if (d != 0) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1) >> shift], 1u);
+      if (d != 0) atomicAdd(&h[(uint32_t)((d < 0 ? -d : d) - 1) & gmask], 1u);
     });
   __syncthreads();
   uint32_t v = 0, incl = 0;
@@ -86,15 +89,14 @@ __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restri
     h[threadIdx.x] = excl;
   }
   __syncthreads();
-  const uint32_t key_mask = (1u << shift) - 1u;
   if (live)
     recode_scalar<Fr>(scalars, i, mont, c, D, K, &dense, [&](int j, int d) {
       if (d != 0) {
         const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
-        const uint32_t pos = atomicAdd(&h[b >> shift], 1u);
+        const uint32_t pos = atomicAdd(&h[b & gmask], 1u);
         buf_ent[pos] = ((uint32_t)j * table_n + first + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
-        buf_key[pos] = (uint16_t)(b & key_mask);
-        buf_bin[pos] = (uint8_t)(b >> shift);
+        buf_key[pos] = (uint16_t)(b >> gbits);
+        buf_bin[pos] = (uint8_t)(b & gmask);
       }
     });
   __syncthreads();
