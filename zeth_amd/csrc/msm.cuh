@@ -154,8 +154,10 @@ inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
   p.gbits = bucket_bits - p.shift;
   p.W = 1 << p.gbits;
   size_t L = p.E >> 18;
-  const size_t load2 = 2 * (p.E >> bucket_bits);  // twice the mean bucket load: an ordinary bucket stays one unit
-  if (L < load2) L = load2;
+  // at least a quarter of the mean bucket load: ordinary buckets then split into about four units (the serial fold of
+  // k_combine_light), not into more than COMBINE_SERIAL_MAX (every bucket on the tree path: 46 ms at 2^19 points, c = 16)
+  const size_t load4 = (p.E >> bucket_bits) / 4;
+  if (L < load4) L = load4;
   if (L < 32) L = 32;
   if (L > 1024) L = 1024;
   if (const char* e = getenv("ZG_MSM_UNIT_LEN")) {

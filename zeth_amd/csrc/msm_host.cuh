@@ -332,8 +332,10 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   {
     uint32_t chunks = (p.cap + COMBINE_CHUNK - 1) / COMBINE_CHUNK;
     if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 128), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 128), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
+    // up to 1024 heavy buckets side by side (the 4096 values of a 12-bit top digit are heavy from 2^25 points on);
+    // workgroups beyond the heavy count or a bucket's chunk count leave at once
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
     if (WN / Wn / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK || (tab && WN / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK))  // more than 2^18 units in one bucket: a third level
       hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L,
                          COMBINE_CHUNK * COMBINE_CHUNK, part);
