@@ -27,7 +27,10 @@
 namespace zg {
 
 static constexpr int MSM_MAX_C = 16;
-static constexpr uint32_t COMBINE_SERIAL_MAX = 8;  // units folded serially by the first unit's lane; more: tree (k_combine_tree)
+// units of a bucket folded serially by the first unit's lane (MsmPlan::smax); more: tree (k_combine_tree).  The tree is
+// built for a few buckets of thousands of units (the "1" of a witness); the thousands of moderately split buckets of a
+// table-mode top digit (11 units at 2^25 points, 22 at 2^26) took it 8 ms against 0.4-0.8 ms folded serially.
+static constexpr uint32_t COMBINE_SERIAL_MAX = 8, COMBINE_SERIAL_MAX_TABLE = 32;
 static constexpr uint32_t COMBINE_CHUNK = 512;     // units per workgroup and launch of the tree
 // Units are handed to the accumulation kernel longest first, by length class: class UNIT_CLASSES = full-length units,
 // classes 0..1023 = partial units by (len - 1) * 1024 / L -- one class per length, since L <= 1024: the lanes of a wave
@@ -57,6 +60,7 @@ struct MsmPlan {
   uint32_t nchunk; // histogram/scatter chunks per window
   uint32_t T;      // bucket segments per window (reduce1 lanes per window)
   uint32_t k;      // buckets per segment
+  uint32_t smax;   // units folded serially (COMBINE_SERIAL_MAX or COMBINE_SERIAL_MAX_TABLE)
   AddConst K;
   // fixed-base table mode (msm_make_table_plan): c = digit width (up to 22), D = digits per scalar, all digits share ONE
   // set of 2^(c-1) buckets, cut into W "bucket groups" of nb <= 2^15 buckets that the sort, the unit table, the
@@ -101,6 +105,7 @@ inline int msm_pick_c(size_t n) {
 inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   MsmPlan p{};
   p.n = n;
+  p.smax = COMBINE_SERIAL_MAX;
   int c = msm_pick_c(n);
   if (force_c) c = force_c;
   p.c = c;
@@ -145,6 +150,7 @@ inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
   MsmPlan p{};
   p.n = n;
   p.table = 1;
+  p.smax = COMBINE_SERIAL_MAX_TABLE;
   p.c = c;
   p.D = D;
   p.E = n * (size_t)D;
@@ -590,7 +596,8 @@ static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict
                                                 uint32_t nb, uint32_t W, uint32_t L, uint32_t cap,
                                                 UnitDesc* __restrict__ units, uint32_t* __restrict__ lencur,
                                                 uint32_t* __restrict__ order /* [W][cap]: unit ids, longest first */,
-                                                uint32_t* __restrict__ heavy /* [0] = count, then ids of heavy buckets */) {
+                                                uint32_t* __restrict__ heavy /* [0] = count, then ids of heavy buckets */,
+                                                uint32_t smax) {
   __shared__ uint32_t lc[UNIT_CLASSES], gb[UNIT_CLASSES];
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = g < (size_t)nb * W;
@@ -602,12 +609,12 @@ static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict
   for (uint32_t q = threadIdx.x; q < UNIT_CLASSES; q += blockDim.x) lc[q] = 0;
   __syncthreads();
   if (v) {
-    if (full + (rem ? 1 : 0) > COMBINE_SERIAL_MAX) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)g;
-    const uint32_t mine = full < COMBINE_SERIAL_MAX ? full : COMBINE_SERIAL_MAX;
+    if (full + (rem ? 1 : 0) > smax) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)g;
+    const uint32_t mine = full < smax ? full : smax;
     for (uint32_t k = 0; k < mine; k++) emit_full_unit(k, (uint32_t)g, w, u0, start, fr, L, cap, units, lencur, order);
   }
   // the partial unit (index `full`), unless it belongs to k_units_heavy
-  const bool partial = v && rem && full < COMBINE_SERIAL_MAX;
+  const bool partial = v && rem && full < smax;
   const uint32_t cls = partial ? unit_class(rem, L) : 0;
   uint32_t rank = 0;
   if (partial && one_window) rank = atomicAdd(&lc[cls], 1u);
@@ -631,7 +638,7 @@ static __global__ void __launch_bounds__(256) k_units_heavy(const uint32_t* __re
                                                       const uint32_t* __restrict__ ufirst, const uint32_t* __restrict__ ffirst,
                                                       uint32_t nb, uint32_t L, uint32_t cap, UnitDesc* __restrict__ units,
                                                       uint32_t* __restrict__ lencur, uint32_t* __restrict__ order,
-                                                      const uint32_t* __restrict__ heavy) {
+                                                      const uint32_t* __restrict__ heavy, uint32_t smax) {
   const uint32_t nheavy = heavy[0];
   for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
     const uint32_t g = heavy[1 + hi];
@@ -639,7 +646,7 @@ static __global__ void __launch_bounds__(256) k_units_heavy(const uint32_t* __re
     const uint32_t full = v / L, rem = v % L;
     const uint32_t nu = full + (rem ? 1 : 0);
     const uint32_t u0 = ufirst[g], start = boff[g], fr = ffirst[g];
-    for (uint32_t k = COMBINE_SERIAL_MAX + blockIdx.x * blockDim.x + threadIdx.x; k < nu; k += gridDim.x * blockDim.x) {
+    for (uint32_t k = smax + blockIdx.x * blockDim.x + threadIdx.x; k < nu; k += gridDim.x * blockDim.x) {
       if (k < full) {
         emit_full_unit(k, g, w, u0, start, fr, L, cap, units, lencur, order);
       } else {
@@ -747,7 +754,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
                                                         uint32_t W, uint32_t cap, const uint32_t* __restrict__ cnt,
                                                         const uint32_t* __restrict__ ufirst, uint32_t L,
-                                                        XYZZ<F>* __restrict__ part) {
+                                                        XYZZ<F>* __restrict__ part, uint32_t smax) {
   if (wunits[W] <= 1) return;  // no bucket has more than one unit
   const uint32_t w = blockIdx.y;
   const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,7 +763,7 @@ __global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restric
   const uint32_t b = units[u].bucket;
   if (ufirst[b] != u) return;  // only a bucket's first unit
   const uint32_t nu = (cnt[b] + L - 1) / L;
-  if (nu < 2 || nu > COMBINE_SERIAL_MAX) return;
+  if (nu < 2 || nu > smax) return;
   XYZZ<F> a = part[u];
   for (uint32_t k = 1; k < nu; k++) {
     XYZZ<F> c = part[u + k];
@@ -769,7 +776,10 @@ __global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restric
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
-                                                       uint32_t L, uint32_t stride, XYZZ<F>* __restrict__ part) {
+                                                       uint32_t L, uint32_t stride, XYZZ<F>* __restrict__ part,
+                                                       const uint32_t* __restrict__ max_units /* most units in any bucket */) {
+  // chunk slots beyond the longest bucket have nothing to do in any heavy bucket
+  if ((size_t)blockIdx.x * COMBINE_CHUNK * stride >= max_units[0]) return;
   const uint32_t nheavy = heavy[0];
   for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
     const uint32_t g = heavy[1 + hi];

@@ -313,9 +313,9 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   }
   ctx->mark("units");
   hipLaunchKernelGGL(k_units, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb,
-                     (uint32_t)p.W, p.L, p.cap, units, lencur, order, heavy);
+                     (uint32_t)p.W, p.L, p.cap, units, lencur, order, heavy, p.smax);
   hipLaunchKernelGGL(k_units_heavy, dim3(8, 128), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb, p.L, p.cap, units, lencur,
-                     order, heavy);
+                     order, heavy, p.smax);
   ctx->mark("accum");
   const dim3 ablk(ZG_ACCUM_BLOCK);
   const uint32_t ablocks = (p.cap + ZG_ACCUM_BLOCK - 1) / ZG_ACCUM_BLOCK;
@@ -328,17 +328,17 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   }
   ctx->mark("combine");
   hipLaunchKernelGGL((k_combine_light<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
-                     p.cap, cnt, ufirst, p.L, part);
+                     p.cap, cnt, ufirst, p.L, part, p.smax);
   {
     uint32_t chunks = (p.cap + COMBINE_CHUNK - 1) / COMBINE_CHUNK;
     if (chunks > 64) chunks = 64;
     // up to 1024 heavy buckets side by side (the 4096 values of a 12-bit top digit are heavy from 2^25 points on);
     // workgroups beyond the heavy count or a bucket's chunk count leave at once
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part);
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part, wunits + p.W);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part, wunits + p.W);
     if (WN / Wn / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK || (tab && WN / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK))  // more than 2^18 units in one bucket: a third level
       hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L,
-                         COMBINE_CHUNK * COMBINE_CHUNK, part);
+                         COMBINE_CHUNK * COMBINE_CHUNK, part, wunits + p.W);
   }
   ctx->mark("reduce1");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
