@@ -393,6 +393,14 @@ public:
     resident_bases &operator=(const resident_bases &) = delete;
     size_t size() const { return size_; }
 
+    /// Fixed-base table (zg_bases_precompute): worth its memory (12-16 times the bases) from about 2^21 bases, which
+    /// are multiplied many times -- the queries of a large proving key.  Results of multi_exp do not change.
+    void precompute(int window_bits = 0)
+    {
+        std::lock_guard<std::mutex> lock(dc_.mutex());
+        check(zg_bases_precompute(handle_, window_bits));
+    }
+
     /// sum_i fs[i] * gs[first + i]
     GroupT multi_exp(const Fr<ppT> *fs, size_t n, size_t first = 0) const
     {

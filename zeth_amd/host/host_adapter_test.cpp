@@ -107,6 +107,11 @@ template<typename ppT, typename GroupT> int cmd_multi_exp(char **argv)
         std::cerr << "resident_bases::multi_exp disagrees with multi_exp\n";
         return 1;
     }
+    rb.precompute(12);  // the same through a fixed-base table
+    if (rb.multi_exp(fs) != sum) {
+        std::cerr << "resident_bases::multi_exp with a table disagrees with multi_exp\n";
+        return 1;
+    }
     if (!fs.empty() && multi_exp<ppT, GroupT>(gs.begin(), gs.begin() + fs.size(), fs.begin(), fs.end()) != sum) {
         std::cerr << "iterator multi_exp disagrees with multi_exp\n";
         return 1;
