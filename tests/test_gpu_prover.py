@@ -142,6 +142,28 @@ def test_random_r1cs_witness_map_and_proof(ctx, curve, ni, na, nc):
     dpk.free()
 
 
+@pytest.mark.parametrize("curve,ni,na,nc", [("alt-bn128", 3, 1500, 2500), ("bls12-377", 1, 600, 1000)])
+def test_proof_with_h_query_table(ctx, curve, ni, na, nc, monkeypatch):
+    """Large keys keep their H query as a fixed-base table (prover.cuh; threshold lowered here through
+    ZG_PK_TABLE_MIN so that a small circuit takes that path): same proof bytes as the oracle, also from a clone."""
+    import zeth_amd
+
+    monkeypatch.setenv("ZG_PK_TABLE_MIN", "1023")
+    cid, C = CURVES[curve]
+    rng = random.Random(ni * 7 + nc)
+    cs, primary, aux = random_r1cs(C, rng, ni, na, nc)
+    snark = zeth_amd.Groth16Snark(ctx, cid)
+    pk, _ = generator_from_secrets_fast(C, cs, rng)
+    dpk = zeth_amd.ProvingKey.from_model(ctx, cid, pk, C.r)
+    r_rand, s_rand = rng.randrange(C.r), rng.randrange(C.r)
+    want = cpu_oracle.prove(cid, C, pk, primary, aux, r_rand, s_rand, chunks=4)
+    assert snark.generate_proof(dpk, primary, aux, r_rand, s_rand) == want
+    twin = dpk.clone()
+    assert snark.generate_proof(twin, primary, aux, r_rand, s_rand) == want
+    twin.free()
+    dpk.free()
+
+
 def generator_from_secrets_fast(C, cs, rng):
     """Key with the right SHAPE for parity tests (sizes, sparsity of B) built from cheap group operations: the
     prover is linear in the key, so parity against the oracle on any key of this shape exercises the same path;

@@ -1,6 +1,9 @@
 # scratch experiments (run on the GPU box)
 cd $GRAFT_REPO_ROOT
-P='import json,sys
-for l in sys.stdin:
-    j=json.loads(l); print(j["log_n"], (j.get("table") or {}).get("window_bits"), round(j["ms"],2), {k:round(v,2) for k,v in j["phases_ms"].items() if k.startswith("red")}, j["verified"])'
-for B in 64 128; do for T in 1024 2048 4096; do echo B=$B T=$T; ZG_REDUCE_BLOCK=$B ZG_MSM_SEGMENTS=$T timeout -k 10 200 python tools/bench_sweep.py g1t 0 21 24 2>/dev/null | python3 -c "$P" || exit 1; done; done
+(while sleep 30; do date >> gpurun_out/tick.log; done) &
+TICK=$!
+trap "kill $TICK" EXIT
+timeout -k 10 300 python -u -m pytest tests/test_gpu_prover.py tests/test_gpu_host_adapter.py -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -2 &&
+timeout -k 10 400 python tools/bench_prove.py --curve bls12-377 --constraints 4194302 --in-flight 0 > gpurun_out/prove_bls377_2p22.json 2> gpurun_out/prove_bls377_2p22.err &&
+cut -c1-900 gpurun_out/prove_bls377_2p22.json &&
+ZG_PK_TABLE_MIN=0 timeout -k 10 400 python tools/bench_prove.py --curve bls12-377 --constraints 4194302 --in-flight 0 --no-cpu --no-verify | cut -c1-400

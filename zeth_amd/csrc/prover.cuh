@@ -101,6 +101,9 @@ struct ProvingKeyDev : PkBase {
   Affine<Fq2T>* B2 = nullptr;
   uint32_t* B_idx = nullptr;
   size_t A_len = 0, B_len = 0, H_len = 0, L_len = 0;
+  // H query as a fixed-base table (msm_table.cuh) when it is large: H then holds H_levels levels of H_len points.  The H
+  // scalars are the only dense ones of a proof (uniform field elements); A, B and L are mostly 0/1 and stay windowed.
+  int H_c = 0, H_levels = 0;
   // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
   Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
   Fr z_inv;
@@ -186,6 +189,29 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(up1(&B1, v->B_g1, v->B_len));
     ZG_TRY(up1(&H, v->H_query, v->H_len));
     ZG_TRY(up1(&L, v->L_query, v->L_len));
+    {
+      // ZG_PK_TABLE_MIN: smallest H query that gets a table (default 2^21 points, where the table starts to pay; 0 = never)
+      const char* e = getenv("ZG_PK_TABLE_MIN");
+      const size_t table_min = e ? strtoull(e, nullptr, 0) : ((size_t)1 << 21);
+      if (table_min && v->H_len >= table_min && v->H_len >= 1024) {
+        int c = 0, D = 0;
+        ZG_TRY(o1->table_params(v->H_len, 0, &c, &D));
+        if ((uint64_t)D * v->H_len < (1ull << 31)) {
+          Affine<Fq>* table = nullptr;
+          ZG_HIP(hipMalloc((void**)&table, (size_t)D * v->H_len * sizeof(Affine<Fq>)));
+          ZG_HIP(hipMemcpyAsync(table, H, v->H_len * sizeof(Affine<Fq>), hipMemcpyDeviceToDevice, st));
+          int s = o1->table_build(ctx, table, v->H_len, c, D);
+          if (s != ZG_OK) {
+            hipFree(table);
+            return s;
+          }
+          hipFree(H);
+          H = table;
+          H_c = c;
+          H_levels = D;
+        }
+      }
+    }
     ZG_TRY(dev_copy(&B2, v->B_g2, v->B_len));
     if (plain && v->B_len) ZG_TRY(o2->to_mont(ctx, B2, v->B_len));
     for (size_t i = 0; i < v->B_len; i++)
@@ -242,6 +268,7 @@ struct ProvingKeyDev : PkBase {
     p->alpha_g1 = alpha_g1; p->beta_g1 = beta_g1; p->delta_g1 = delta_g1; p->beta_g2 = beta_g2; p->delta_g2 = delta_g2;
     p->A = A; p->B1 = B1; p->H = H; p->L = L; p->B2 = B2; p->B_idx = B_idx;
     p->A_len = A_len; p->B_len = B_len; p->H_len = H_len; p->L_len = L_len;
+    p->H_c = H_c; p->H_levels = H_levels;
     int s = p->alloc_scratch();
     if (s == ZG_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = ZG_ERR_HIP;
     if (s != ZG_OK) {
@@ -317,7 +344,8 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(qap_h());
     static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
     static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
-    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, nullptr));
+    const MsmTable h_tab{H_len, 0, H_c, H_levels};
+    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr));
     auto width = [](uint32_t dense) { return lane_c ? lane_c : dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
     ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0]), nullptr));
     ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1]), nullptr));
