@@ -481,9 +481,16 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
   if (threadIdx.x < 128) h[threadIdx.x] = 0;
   __syncthreads();
   const int16_t* d = dig + (size_t)w * n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int v = d[i];
-    if (v != 0) atomicAdd(&h[(uint32_t)((v < 0 ? -v : v) - 1) >> 8], 1u);
+  // one pass: every lane keeps its (up to) 8 digits and their ranks within their bins in registers, so each entry
+  // costs one LDS atomic and the digits are read once
+  constexpr uint32_t PER = SORT_TILE1 / 1024;
+  int my_v[PER];
+  uint32_t my_rank[PER];
+#pragma unroll
+  for (uint32_t r = 0; r < PER; r++) {
+    const size_t i = lo + r * 1024u + threadIdx.x;
+    my_v[r] = i < hi ? (int)d[i] : 0;
+    if (my_v[r] != 0) my_rank[r] = atomicAdd(&h[(uint32_t)((my_v[r] < 0 ? -my_v[r] : my_v[r]) - 1) >> 8], 1u);
   }
   __syncthreads();
   {
@@ -500,22 +507,22 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
       const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
       lstart[threadIdx.x] = excl;
       gbase[threadIdx.x] = v ? atomicAdd(&cursor1[(size_t)w * nhi + threadIdx.x], v) : 0;
-      h[threadIdx.x] = excl;  // running local cursors
     }
     __syncthreads();
   }
-  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int v = d[i];
+#pragma unroll
+  for (uint32_t r = 0; r < PER; r++) {
+    const int v = my_v[r];
     if (v != 0) {
-      uint32_t b = (uint32_t)((v < 0 ? -v : v) - 1);
-      uint32_t pos = atomicAdd(&h[b >> 8], 1u);
-      buf_ent[pos] = (uint32_t)i | (v < 0 ? 0x80000000u : 0u);
+      const uint32_t b = (uint32_t)((v < 0 ? -v : v) - 1);
+      const uint32_t pos = lstart[b >> 8] + my_rank[r];
+      buf_ent[pos] = (uint32_t)(lo + r * 1024u + threadIdx.x) | (v < 0 ? 0x80000000u : 0u);
       buf_lo[pos] = (uint8_t)(b & 255u);
       buf_bin[pos] = (uint8_t)(b >> 8);
     }
   }
   __syncthreads();
-  const uint32_t total = lstart[nhi - 1] + (h[nhi - 1] - lstart[nhi - 1]);
+  const uint32_t total = lstart[nhi - 1] + h[nhi - 1];
   for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
     uint32_t bin = buf_bin[i];
     uint32_t g = gbase[bin] + (i - lstart[bin]);
@@ -541,7 +548,21 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
     if (hi > end) hi = end;
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[mid_lo[i]], 1u);
+    // one pass over the tile: every lane keeps its (up to) 8 entries and their ranks within their bins in registers, so
+    // each entry costs one LDS atomic and one read of the intermediate arrays
+    constexpr uint32_t PER = SORT_TILE2 / 1024;
+    uint32_t my_ent[PER], my_rank[PER];
+    uint32_t my_bin[PER];
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+      const uint32_t i = lo + r * 1024u + threadIdx.x;
+      my_bin[r] = 0xFFFFFFFFu;
+      if (i < hi) {
+        my_bin[r] = mid_lo[i];
+        my_ent[r] = mid_ent[i];
+        my_rank[r] = atomicAdd(&h[my_bin[r]], 1u);
+      }
+    }
     __syncthreads();
     {
       // exclusive scan of the 256 counts: wave prefix sums by the first four waves, then the waves' totals
@@ -558,15 +579,16 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
         const uint32_t excl = off + incl - v;
         lstart[threadIdx.x] = excl;
         gbase[threadIdx.x] = v ? atomicAdd(&cur[threadIdx.x], v) : 0;
-        h[threadIdx.x] = excl;
       }
       __syncthreads();
     }
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      uint32_t bin = mid_lo[i];
-      uint32_t pos = atomicAdd(&h[bin], 1u);
-      buf_ent[pos] = mid_ent[i];
-      buf_bin[pos] = (uint8_t)bin;
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+      if (my_bin[r] != 0xFFFFFFFFu) {
+        const uint32_t pos = lstart[my_bin[r]] + my_rank[r];
+        buf_ent[pos] = my_ent[r];
+        buf_bin[pos] = (uint8_t)my_bin[r];
+      }
     }
     __syncthreads();
     const uint32_t total = hi - lo;

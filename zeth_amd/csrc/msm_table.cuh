@@ -167,7 +167,19 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi_table(const uint32_t
     const uint32_t hi = lo + SORT_TILE1 < end ? lo + SORT_TILE1 : end;
     if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&h[fkey[q] >> 8], 1u);
+    // one pass: entries, keys and ranks within their bins stay in registers (one LDS atomic per entry)
+    constexpr uint32_t PER = SORT_TILE1 / 1024;
+    uint32_t my_ent[PER], my_key[PER], my_rank[PER];
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+      const uint32_t q = lo + r * 1024u + threadIdx.x;
+      my_key[r] = 0xFFFFFFFFu;
+      if (q < hi) {
+        my_key[r] = fkey[q];
+        my_ent[r] = fent[q];
+        my_rank[r] = atomicAdd(&h[my_key[r] >> 8], 1u);
+      }
+    }
     __syncthreads();
     uint32_t v = 0, incl = 0;
     if (threadIdx.x < 128) {
@@ -180,15 +192,16 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi_table(const uint32_t
       const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
       lstart[threadIdx.x] = excl;
       gbase[threadIdx.x] = v ? atomicAdd(&cursor1[(size_t)w * nhi + threadIdx.x], v) : 0;
-      h[threadIdx.x] = excl;
     }
     __syncthreads();
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
-      const uint32_t b = fkey[q];
-      const uint32_t pos = atomicAdd(&h[b >> 8], 1u);
-      buf_ent[pos] = fent[q];
-      buf_lo[pos] = (uint8_t)(b & 255u);
-      buf_bin[pos] = (uint8_t)(b >> 8);
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+      if (my_key[r] != 0xFFFFFFFFu) {
+        const uint32_t pos = lstart[my_key[r] >> 8] + my_rank[r];
+        buf_ent[pos] = my_ent[r];
+        buf_lo[pos] = (uint8_t)(my_key[r] & 255u);
+        buf_bin[pos] = (uint8_t)(my_key[r] >> 8);
+      }
     }
     __syncthreads();
     const uint32_t total = hi - lo;
