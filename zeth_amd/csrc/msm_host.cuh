@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.cuh"
 #include "msm.cuh"
 #include "msm_table.cuh"
@@ -226,14 +228,15 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
 
   hipStream_t st = ctx->stream;
   const size_t lds = (size_t)p.nb * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    ZG_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_hist_table, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_scatter_table, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17));
-    attr_done = true;
-  }
+  static std::once_flag attr_once;  // several lanes of a proof may arrive here at once
+  hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [&] {
+    attr_err = hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
+    if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
+    if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_hist_table, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
+    if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_scatter_table, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
+  });
+  ZG_HIP(attr_err);
   ctx->prof_begin();
   ctx->mark("digits");
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <thread>
 
 #include "msm_host.cuh"
 #include "ntt_host.cuh"
@@ -341,16 +342,40 @@ struct ProvingKeyDev : PkBase {
     // 0/1 filter plays in multi_exp_with_mixed_addition.  Any width gives the same group element.
     // the longest dependent chain (constraint evaluation, seven transforms, H evaluation) goes first, on the
     // high-priority main stream; the side lanes have the lowest stream priority
-    ZG_TRY(qap_h());
     static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
     static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
-    const MsmTable h_tab{H_len, 0, H_c, H_levels};
-    ZG_TRY(o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr));
     auto width = [](uint32_t dense) { return lane_c ? lane_c : dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
-    ZG_TRY(o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0]), nullptr));
-    ZG_TRY(o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1]), nullptr));
-    ZG_TRY(o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2]), nullptr));
-    ZG_TRY(o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3]), nullptr));
+    // A proof is ~100 kernel launches and the host needs 20-35 us for each: queued from one thread, the last lane's
+    // first kernel started 3.3 ms after the proof began (rocprofv3 timeline, JoinSplit scale) although its input was
+    // ready after 0.05 ms.  Every lane is therefore queued by a thread of its own while this thread queues the H chain.
+    int lane_status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
+    auto queue_lane = [&](int i) {
+      if (hipSetDevice(ctx->device) != hipSuccess) {
+        lane_status[i] = ZG_ERR_HIP;
+        return;
+      }
+      switch (i) {
+        case 0: lane_status[0] = o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0]), nullptr); break;
+        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1]), nullptr); break;
+        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2]), nullptr); break;
+        default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3]), nullptr); break;
+      }
+    };
+    static const bool serial_queue = getenv("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
+    std::thread workers[4];
+    if (!serial_queue)
+      for (int i = 0; i < 4; i++) workers[i] = std::thread(queue_lane, i);
+    int h_status = qap_h();
+    const MsmTable h_tab{H_len, 0, H_c, H_levels};
+    if (h_status == ZG_OK) h_status = o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr);
+    for (int i = 0; i < 4; i++) {
+      if (serial_queue)
+        queue_lane(i);
+      else
+        workers[i].join();
+    }
+    ZG_TRY(h_status);
+    for (int i = 0; i < 4; i++) ZG_TRY(lane_status[i]);
     stamp("all work queued");
     // Host tail, ordered so that everything that does not need a device result runs while the GPU is busy:
     // the four blinding multiples of delta first, then each evaluation as its lane completes.
