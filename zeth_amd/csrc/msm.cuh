@@ -10,12 +10,15 @@
 //   k_digits   scalar -> W signed c-bit digits (int16), via s + sum_w 2^(c-1) 2^(wc) then per-window re-centre
 //   k_hist     per (chunk, window) LDS histogram of |digit| (128 KB of LDS at c = 16) -> global counts
 //   k_scan     per window exclusive scan -> bucket offsets, work-unit offsets (a unit = <= L entries of one bucket)
-//   k_scatter  counting-sort scatter of (point index | sign) through LDS cursors
-//   k_units    unit table
+//   k_scatter  counting-sort scatter of (point index | sign) through LDS cursors; from 512 buckets per window the
+//              two-level form k_scatter_hi / k_scatter_lo (tiles ranked in LDS, written out in runs)
+//   k_units, k_units_heavy   unit table and the longest-first order of the units
 //   k_accum    one lane per unit: gather affine bases (64-byte AoS records), XYZZ mixed add      <- dominant
-//   k_reduce1  per (window, bucket segment): combine units, running-sum, weight by segment start
+//   k_combine_light, k_combine_tree   fold the units of split buckets into their first unit
+//   k_reduce1  per (window, bucket segment): running sums, weight by segment start
 //   k_reduce2  per window tree reduction -> W window sums
 // Host tail: Horner over the W window sums (c doublings each) and normalisation to affine.
+// Fixed bases with a table of precomputed multiples: one bucket set for all digits, msm_table.cuh.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
