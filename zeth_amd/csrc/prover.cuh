@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <system_error>
 #include <thread>
 
 #include "msm_host.cuh"
@@ -363,16 +364,23 @@ struct ProvingKeyDev : PkBase {
     };
     static const bool serial_queue = getenv("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
     std::thread workers[4];
-    if (!serial_queue)
-      for (int i = 0; i < 4; i++) workers[i] = std::thread(queue_lane, i);
+    if (!serial_queue) {
+      for (int i = 0; i < 4; i++) {
+        try {
+          workers[i] = std::thread(queue_lane, i);
+        } catch (const std::system_error&) {
+          // no thread to be had: this lane is queued by the calling thread below (no exception crosses the C ABI)
+        }
+      }
+    }
     int h_status = qap_h();
     const MsmTable h_tab{H_len, 0, H_c, H_levels};
     if (h_status == ZG_OK) h_status = o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr);
     for (int i = 0; i < 4; i++) {
-      if (serial_queue)
-        queue_lane(i);
-      else
+      if (workers[i].joinable())
         workers[i].join();
+      else
+        queue_lane(i);
     }
     ZG_TRY(h_status);
     for (int i = 0; i < 4; i++) ZG_TRY(lane_status[i]);
