@@ -155,3 +155,30 @@ def test_table_msm_degenerate_scalar_sets_at_size(ctx):
     total = (int(vals.astype(object).sum()) * t0 + d * int((vals.astype(object) * idx).sum())) % r
     assert run(w) == C.G1.mul(total, C.G1.gen)
     bases.free()
+
+
+@pytest.mark.parametrize("curve", ["alt-bn128", "bls12-377"])
+def test_table_msm_scalar_forms_and_memories(ctx, curve):
+    """The same scalars as plain integers in host memory, as Montgomery residues (libff's in-memory form, what a Zeth
+    caller hands over), and resident in device memory (the benchmark's path): one group element."""
+    import zeth_amd
+    from zeth_amd.lib import FORM_MONT
+    from zeth_amd.synth import closed_form_scalar, random_scalars_host
+
+    cid, C = CURVES[curve]
+    n = 1 << 15
+    t0, d = 0x1234567890ABCDEF1234567, 0xFEDCBA987654321
+    bases = zeth_amd.Bases.generate(ctx, cid, 1, n, t0, d).precompute(20)
+    dev = zeth_amd.DeviceBuffer.random_scalars(ctx, cid, n, 77)
+    words = random_scalars_host(n, C.r, 77)
+    want = C.G1.mul(closed_form_scalar(words, t0, d, C.r), C.G1.gen)
+    assert bases.msm(dev, n=n) == want
+    ints = [int(w[0]) | int(w[1]) << 64 | int(w[2]) << 128 | int(w[3]) << 192 for w in words]
+    assert bases.msm(ints) == want
+    mont = [(s << 256) % C.r for s in ints]
+    assert bases.msm(mont, form=FORM_MONT) == want
+    # a sub-range from device memory: scalars [0, n/2) against bases [n/4, 3n/4)
+    k = sum(a * (t0 + (n // 4 + i) * d) for i, a in enumerate(ints[: n // 2])) % C.r
+    assert bases.msm(dev, first=n // 4, n=n // 2) == C.G1.mul(k, C.G1.gen)
+    dev.free()
+    bases.free()
