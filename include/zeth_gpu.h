@@ -89,7 +89,7 @@ int zg_bases_read(zg_bases* b, size_t first, size_t count, int form, void* out);
  * it exists because the bases of a proving key never change (libsnark r1cs_gg_ppzksnark_proving_key's A/B/H/L queries,
  * loaded once at prover_server.cpp:449-493) and HBM is large: the library keeps the multiples 2^(j*c) P_i, j < D =
  * ceil((bits + 2) / c), of every base, so that an MSM sorts all n*D digit terms into ONE set of 2^(c-1) buckets and
- * needs D = 12 mixed additions per 254-bit scalar at c = 22 instead of 16-17.  Costs D times the base memory (12.9 GB
+ * needs D = 12 mixed additions per 254-bit scalar at c = 22 (13 at c = 20) instead of 16-17.  Costs D times the base memory (12.9 GB
  * for 2^24 BN254 G1 points) and one pass of D*c doublings per base.  window_bits: 0 = chosen from the number of bases,
  * else 10..22.  Results of zg_msm are unchanged (same group element); zg_bases_read still returns the bases.
  * Calling it again is a no-op (ZG_ERR_INVALID_ARGUMENT if a different width is asked for). */
@@ -147,7 +147,7 @@ typedef struct {
 /* Uploads the proving key once (bases to HBM in Montgomery affine form, constraint matrices as CSR) and allocates
  * the per-proof device scratch: the analogue of loading the keypair before proving (zeth_tool/prove_cmd.cpp:39-43,
  * prover_server/prover_server.cpp:449-493).  Size mismatches -> ZG_ERR_INVALID_ARGUMENT.
- * An H query of 2^21 points or more is kept as a fixed-base table (see zg_bases_precompute; 12-13 times its memory);
+ * An H query of 2^18 points or more is kept as a fixed-base table (see zg_bases_precompute; 12-13 times its memory);
  * the environment variable ZG_PK_TABLE_MIN sets another threshold (0 = never). */
 int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out);
 void zg_pk_free(zg_pk* pk);

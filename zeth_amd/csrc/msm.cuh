@@ -83,12 +83,12 @@ inline int msm_table_digits(int scalar_bits, int c) { return (scalar_bits + 2 + 
 static constexpr int MSM_TABLE_MIN_C = 10, MSM_TABLE_MAX_C = 22;
 
 // Digit width of the table for N fixed bases, measured on MI355X (BN254 G1, tools/bench_sweep.py g1t): 22 from 2^23
-// bases (12 digits, 2^21 buckets), 20 from 2^21 (13 digits), 17 below (16 digits, where the table saves no additions and
-// only the per-window reductions).  Widths whose top digit is nearly empty are avoided: at c = 21 the 13th digit has
-// 2 bits, four buckets take a quarter of all scalars each, and the accumulation runs 60 % longer than at c = 20.
+// bases (12 digits, 2^21 buckets), 20 below (13 digits, 2^19 buckets: best at every size from 2^16 to 2^22 -- 2^20 points
+// 2.56 ms against 3.1 ms at c = 17 and 3.0 ms windowed).  Widths whose top digit is nearly empty are avoided: at c = 21
+// the 13th digit has 2 bits, four buckets take a quarter of all scalars each, and the accumulation runs 60 % longer.
 inline int msm_table_pick_c(size_t N) {
   int lg = ilog2_floor(N ? N : 1) + ((N & (N - 1)) ? 1 : 0);
-  return lg >= 23 ? 22 : lg >= 21 ? 20 : 17;
+  return lg >= 23 ? 22 : 20;
 }
 
 // window width for n scalars that are not 0 or 1, tuned on MI355X (tools/tune_c.py): odd widths keep the
