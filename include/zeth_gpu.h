@@ -119,6 +119,15 @@ int zg_msm_ex(zg_bases* bases, size_t first, const void* scalars, size_t n, int 
  * log_n beyond the field's two-adicity (28 / 47) or this build's limit (2^24) -> ZG_ERR_UNSUPPORTED. */
 int zg_ntt(zg_ctx* ctx, int curve, void* data, unsigned log_n, int inverse, int coset, int form, int mem);
 
+/* zg_ntt on device memory (d_data: 2^log_n Fr elements in HBM, transformed in place) for callers that cannot allocate:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * It calls no hipMalloc / hipFree / allocating routine: the domain's twiddle and coset tables and the transform buffer
+ * live in a static device array of 4,227,072 bytes that every GPU the library runs on holds until the process ends.
+ * Limit: log_n <= 16 (ZG_ERR_UNSUPPORTED beyond).  All calls on one GPU share that array (whatever their context), so
+ * calls that overlap on one GPU race; the array keeps the last call's tables and rebuilds them, with kernels only, when
+ * another (curve, log_n) is asked for.  Results are those of zg_ntt. */
+int zg_ntt_noalloc(zg_ctx* ctx, int curve, void* d_data, unsigned log_n, int inverse, int coset, int form);
+
 /* One R1CS matrix in CSR form: row i (constraint i) holds the terms of its linear combination, `col` = variable
  * index with 0 = the constant ONE (libsnark linear_term.index), `val` = Fr coefficient.  The on-disk equivalent is
  * libzeth/serialization/r1cs_serialization.tcc:199-275. */

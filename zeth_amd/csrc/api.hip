@@ -1,9 +1,39 @@
 // C ABI (include/zeth_gpu.h): argument checking, contexts, resident bases, MSM entry points.
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "common.cuh"
+
+// ---- static scratch of the allocation-free entry point (zg_ntt_noalloc) --------------------------------------
+// One array per GPU the code object is loaded on, held until the process ends: the twiddle/coset tables of one
+// (curve, log n <= 16) domain followed by the 2^16-element transform buffer (ntt_host.cuh, ntt_static_bytes()).
+// `scratch` is a host-side stand-in for the symbol, never a device address: every use below goes through the pointer
+// hipGetSymbolAddress returned for the device in question.
+static constexpr size_t ZG_STATIC_SCRATCH_BYTES = (((size_t)1 << 16) + ((size_t)1 << 16) + 4 * 256) * 32;  // 4,227,072
+static __device__ __align__(256) unsigned char scratch[ZG_STATIC_SCRATCH_BYTES];
+
+static constexpr int ZG_MAX_DEVICES = 64;
+struct StaticScratch {
+  void* ptr = nullptr;  // this device's copy of `scratch`
+  int tag_curve = -1;   // domain whose tables the scratch holds (-1: none)
+  unsigned tag_log_m = 0;
+};
+static StaticScratch g_static[ZG_MAX_DEVICES];
+static std::mutex g_static_mu;
+
+// with `device` current: resolve the device address of `scratch` once per device
+static int static_scratch_resolve(int device) {
+  if (device < 0 || device >= ZG_MAX_DEVICES) return ZG_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  if (g_static[device].ptr) return ZG_OK;
+  void* p = nullptr;
+  ZG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+  if (!p) return ZG_ERR_HIP;
+  g_static[device].ptr = p;
+  return ZG_OK;
+}
 
 const GroupOps *ZG_OPS_BN254_G1(), *ZG_OPS_BN254_G2(), *ZG_OPS_BLS377_G1(), *ZG_OPS_BLS377_G2();
 
@@ -52,6 +82,7 @@ int zg_ctx_create_prio(int device, int prio, zg_ctx** out) {
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZG_ERR_NO_DEVICE;
   if (device < 0 || device >= count) return ZG_ERR_INVALID_ARGUMENT;
   ZG_HIP(hipSetDevice(device));
+  ZG_TRY(static_scratch_resolve(device));
   zg_ctx* c = new (std::nothrow) zg_ctx();
   if (!c) return ZG_ERR_OUT_OF_MEMORY;
   c->device = device;
@@ -392,6 +423,19 @@ int zg_ntt(zg_ctx* ctx, int curve, void* data, unsigned log_n, int inverse, int 
   if (s == ZG_OK && hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = ZG_ERR_HIP;
   hipFree(d);
   return s;
+}
+
+int zg_ntt_noalloc(zg_ctx* ctx, int curve, void* d_data, unsigned log_n, int inverse, int coset, int form) {
+  const FrOps* ops = zg_fr_ops(curve);
+  if (!ctx || !ops || !d_data || (form != ZG_FORM_PLAIN && form != ZG_FORM_MONT)) return ZG_ERR_INVALID_ARGUMENT;
+  if (log_n > 16) return ZG_ERR_UNSUPPORTED;  // the static scratch holds one domain of at most 2^16 points
+  if (ctx->device < 0 || ctx->device >= ZG_MAX_DEVICES) return ZG_ERR_UNSUPPORTED;
+  if (ops->ntt_static_bytes() > ZG_STATIC_SCRATCH_BYTES) return ZG_ERR_UNSUPPORTED;
+  ZG_HIP(hipSetDevice(ctx->device));
+  StaticScratch& sc = g_static[ctx->device];  // ptr was resolved when this context was created
+  if (!sc.ptr) return ZG_ERR_HIP;
+  return ops->ntt_static(ctx, curve, d_data, log_n, inverse != 0, coset != 0, form, sc.ptr, ZG_STATIC_SCRATCH_BYTES,
+                         &sc.tag_curve, &sc.tag_log_m);
 }
 
 int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out) {

@@ -181,6 +181,10 @@ struct zg_pk {
 struct FrOps {
   int (*ntt_inplace)(zg_ctx*, int curve, void* d_data, unsigned log_m, int inverse, int coset, int form);
   int (*pk_create)(zg_ctx*, int curve, const zg_pk_view* view, PkBase** out);
+  // zg_ntt_noalloc: tables and transform buffer inside `scratch`; the tags name the domain whose tables it holds
+  int (*ntt_static)(zg_ctx*, int curve, void* d_data, unsigned log_m, int inverse, int coset, int form, void* scratch,
+                    size_t scratch_bytes, int* tag_curve, unsigned* tag_log_m);
+  size_t (*ntt_static_bytes)();
 };
 const FrOps* zg_fr_ops(int curve);
 

@@ -1,6 +1,8 @@
 // Host driver for the Fr evaluation-domain transforms: per-(curve, log m) twiddle tables cached in the context
 // (the analogue of constructing a libfqfft::basic_radix2_domain<Fr>(m) once), launch geometry, fused scalings.
 #pragma once
+#include <mutex>
+
 #include "common.cuh"
 #include "ntt.cuh"
 
@@ -43,32 +45,32 @@ inline uint32_t ntt_pick_tile(uint32_t n_this, uint32_t n_other) {
   return t;
 }
 
+// split of log m over the two passes; false when this build cannot run the size
+inline bool ntt_split(unsigned log_m, unsigned* l1, unsigned* l2) {
+  *l1 = log_m <= 12 ? log_m : (log_m + 1) / 2;
+  *l2 = log_m - *l1;
+  return *l1 <= 12;
+}
+
+// Fr elements of table storage a domain of 2^log_m points needs: w^i and w^-i (m/2 each), the four coset tables
+inline size_t ntt_table_elems(unsigned log_m) {
+  unsigned l1 = 0, l2 = 0;
+  ntt_split(log_m, &l1, &l2);
+  const size_t m = (size_t)1 << log_m, half = m > 1 ? m / 2 : 1;
+  return 2 * half + 2 * ((size_t)1 << l1) + 2 * ((size_t)1 << l2);
+}
+
+// Points D at `storage` (ntt_table_elems(log_m) elements) and, when `fill` is set, queues the kernels that compute the
+// tables there on the context's stream (fill = false: the storage already holds this domain's tables).
 template <class Fr>
-int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) {
+int ntt_fill_tables(zg_ctx* ctx, unsigned log_m, Fr* storage, NttDomain<Fr>* D, bool fill = true) {
   using P = typename Fr::Params;
-  if (log_m > (unsigned)P::TWO_ADICITY || log_m > 26) return ZG_ERR_UNSUPPORTED;
-  const uint32_t key = ((uint32_t)curve << 8) | log_m;
-  auto it = ctx->ntt_domains.find(key);
-  if (it != ctx->ntt_domains.end()) {
-    *out = static_cast<NttDomain<Fr>*>(it->second);
-    return ZG_OK;
-  }
-  auto* D = new NttDomain<Fr>();
+  unsigned l1 = 0, l2 = 0;
+  if (log_m > (unsigned)P::TWO_ADICITY || log_m > 26 || !ntt_split(log_m, &l1, &l2)) return ZG_ERR_UNSUPPORTED;
   const uint64_t m = 1ull << log_m;
-  const unsigned l1 = log_m <= 12 ? log_m : (log_m + 1) / 2, l2 = log_m - l1;
-  if (l1 > 12) {
-    delete D;
-    return ZG_ERR_UNSUPPORTED;
-  }
   const uint32_t N1 = 1u << l1, N2 = 1u << l2;
   const size_t half = m > 1 ? m / 2 : 1;
-  const size_t total = 2 * half + 2 * (size_t)N1 + 2 * (size_t)N2;
-  hipError_t e = hipMalloc((void**)&D->storage, total * sizeof(Fr));
-  if (e != hipSuccess) {
-    delete D;
-    return e == hipErrorOutOfMemory ? ZG_ERR_OUT_OF_MEMORY : ZG_ERR_HIP;
-  }
-  Fr* p = D->storage;
+  Fr* p = storage;
   Fr* tw = p; p += half;
   Fr* twi = p; p += half;
   Fr* g_hi = p; p += N1;
@@ -88,15 +90,14 @@ int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) 
   auto launch = [&](Fr* dst, Fr base, uint64_t step, Fr scale, uint32_t count) {
     hipLaunchKernelGGL((k_pow_table<Fr>), dim3((count + 255) / 256), dim3(256), 0, st, dst, base, step, scale, count);
   };
-  launch(tw, w, 1, Fr::one(), (uint32_t)half);
-  launch(twi, wi, 1, Fr::one(), (uint32_t)half);
-  launch(g_hi, g, N2, Fr::one(), N1);
-  launch(g_lo, g, 1, Fr::one(), N2);
-  launch(gi_lo, gi, 1, minv, N1);
-  launch(gi_hi, gi, N1, Fr::one(), N2);
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-    delete D;
-    return ZG_ERR_HIP;
+  if (fill) {
+    launch(tw, w, 1, Fr::one(), (uint32_t)half);
+    launch(twi, wi, 1, Fr::one(), (uint32_t)half);
+    launch(g_hi, g, N2, Fr::one(), N1);
+    launch(g_lo, g, 1, Fr::one(), N2);
+    launch(gi_lo, gi, 1, minv, N1);
+    launch(gi_hi, gi, N1, Fr::one(), N2);
+    ZG_HIP(hipGetLastError());
   }
   D->T.log_m = log_m;
   D->T.tw = tw;
@@ -110,6 +111,32 @@ int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) 
   D->T.log_n2 = l2;
   D->TC = ntt_pick_tile(N1, N2);
   D->TR = ntt_pick_tile(N2, N1);
+  return ZG_OK;
+}
+
+template <class Fr>
+int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) {
+  using P = typename Fr::Params;
+  unsigned l1 = 0, l2 = 0;
+  if (log_m > (unsigned)P::TWO_ADICITY || log_m > 26 || !ntt_split(log_m, &l1, &l2)) return ZG_ERR_UNSUPPORTED;
+  const uint32_t key = ((uint32_t)curve << 8) | log_m;
+  auto it = ctx->ntt_domains.find(key);
+  if (it != ctx->ntt_domains.end()) {
+    *out = static_cast<NttDomain<Fr>*>(it->second);
+    return ZG_OK;
+  }
+  auto* D = new NttDomain<Fr>();
+  hipError_t e = hipMalloc((void**)&D->storage, ntt_table_elems(log_m) * sizeof(Fr));
+  if (e != hipSuccess) {
+    delete D;
+    return e == hipErrorOutOfMemory ? ZG_ERR_OUT_OF_MEMORY : ZG_ERR_HIP;
+  }
+  int s = ntt_fill_tables<Fr>(ctx, log_m, D->storage, D);
+  if (s == ZG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = ZG_ERR_HIP;
+  if (s != ZG_OK) {
+    delete D;
+    return s;
+  }
   ctx->ntt_domains[key] = D;
   *out = D;
   return ZG_OK;
@@ -118,16 +145,16 @@ int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) 
 // data (m elements, Montgomery form) is overwritten with pass A's intermediate; the transform lands in `out`.
 template <class Fr>
 int ntt_launch(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::once_flag attr_once;  // clones of a key prove from several threads (zg_pk_clone)
+  hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [&] {
     const int lim = NTT_LDS_ELEMS * 32;
-    ZG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_a<Fr, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_a<Fr, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_b<Fr, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_b<Fr, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    ZG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_b<Fr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    attr_done = true;
-  }
+    const void* kernels[] = {(const void*)k_ntt_pass_a<Fr, false>, (const void*)k_ntt_pass_a<Fr, true>, (const void*)k_ntt_pass_b<Fr, 0>,
+                             (const void*)k_ntt_pass_b<Fr, 1>, (const void*)k_ntt_pass_b<Fr, 2>};
+    for (const void* k : kernels)
+      if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  });
+  ZG_HIP(attr_err);
   const uint32_t N1 = 1u << D->T.log_n1, N2 = 1u << D->T.log_n2;
   const uint32_t TC = D->TC, TR = D->TR;
   hipStream_t st = ctx->stream;
@@ -176,6 +203,47 @@ int ntt_inplace(zg_ctx* ctx, int curve, void* d_data, unsigned log_m, int invers
   ZG_HIP(hipGetLastError());
   ZG_HIP(hipStreamSynchronize(st));
   ctx->prof_end();
+  return ZG_OK;
+}
+
+// The allocation-free form behind zg_ntt_noalloc: the tables of one (curve, log m) and the transform buffer live in
+// `scratch` (the library's static device array, api.hip) instead of hipMalloc'ed memory.  *tag_curve / *tag_log_m say
+// which domain's tables the scratch currently holds; they are rebuilt (kernels only) when another size is asked for.
+static constexpr unsigned NTT_STATIC_MAX_LOG = 16;
+inline size_t ntt_static_table_elems() {
+  size_t mx = 0;
+  for (unsigned l = 0; l <= NTT_STATIC_MAX_LOG; l++) mx = ntt_table_elems(l) > mx ? ntt_table_elems(l) : mx;
+  return mx;
+}
+inline size_t ntt_static_bytes() { return (ntt_static_table_elems() + ((size_t)1 << NTT_STATIC_MAX_LOG)) * 32; }
+
+template <class Fr>
+int ntt_static(zg_ctx* ctx, int curve, void* d_data, unsigned log_m, int inverse, int coset, int form, void* scratch,
+               size_t scratch_bytes, int* tag_curve, unsigned* tag_log_m) {
+  if (log_m > NTT_STATIC_MAX_LOG) return ZG_ERR_UNSUPPORTED;
+  if (scratch_bytes < ntt_static_bytes()) return ZG_ERR_INVALID_ARGUMENT;
+  Fr* tables = reinterpret_cast<Fr*>(scratch);
+  Fr* tmp = tables + ntt_static_table_elems();
+  NttDomain<Fr> D;  // storage stays null: nothing to free
+  const bool cached = *tag_curve == curve && *tag_log_m == log_m;
+  *tag_curve = -1;  // nothing valid until the fill has been queued without error
+  ZG_TRY(ntt_fill_tables<Fr>(ctx, log_m, tables, &D, !cached));
+  *tag_curve = curve;
+  *tag_log_m = log_m;
+  const size_t m = (size_t)1 << log_m;
+  Fr* data = reinterpret_cast<Fr*>(d_data);
+  hipStream_t st = ctx->stream;
+  const unsigned blocks = (unsigned)((m + 255) / 256);
+  const bool prof = ctx->profiling;
+  ctx->profiling = false;  // phase marks create events on demand: not in this entry point
+  if (form == ZG_FORM_PLAIN) hipLaunchKernelGGL((k_fr_convert<Fr>), dim3(blocks), dim3(256), 0, st, data, m, 1);
+  int s = ntt_launch<Fr>(ctx, &D, data, tmp, inverse, coset);
+  ctx->profiling = prof;
+  ZG_TRY(s);
+  ZG_HIP(hipMemcpyAsync(data, tmp, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  if (form == ZG_FORM_PLAIN) hipLaunchKernelGGL((k_fr_convert<Fr>), dim3(blocks), dim3(256), 0, st, data, m, 0);
+  ZG_HIP(hipGetLastError());
+  ZG_HIP(hipStreamSynchronize(st));
   return ZG_OK;
 }
 

@@ -81,6 +81,7 @@ def load_library():
     L.zg_msm.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp]
     L.zg_msm_ex.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp, ci]
     L.zg_ntt.argtypes = [vp, ci, vp, ctypes.c_uint, ci, ci, ci, ci]
+    L.zg_ntt_noalloc.argtypes = [vp, ci, vp, ctypes.c_uint, ci, ci, ci]
     L.zg_pk_create.argtypes = [vp, ci, ctypes.POINTER(PkView), ctypes.POINTER(vp)]
     L.zg_pk_free.argtypes = [vp]
     L.zg_pk_clone.argtypes = [vp, ctypes.POINTER(vp)]
@@ -341,6 +342,13 @@ class EvaluationDomain:
         _check(self.ctx._L.zg_ntt(self.ctx._h, self.curve, buf, self.log_m, int(inverse), int(coset), FORM_PLAIN, MEM_HOST))
         raw = buf.raw
         return [le_to_int(raw[32 * i : 32 * i + 32]) for i in range(self.m)]
+
+    def run_noalloc(self, values: "DeviceBuffer", inverse: bool, coset: bool) -> "DeviceBuffer":
+        """The same transform through zg_ntt_noalloc (static device scratch, m <= 2^16, device memory only)."""
+        assert values.nbytes == 32 * self.m
+        _check(self.ctx._L.zg_ntt_noalloc(self.ctx._h, self.curve, ctypes.c_void_p(values.ptr), self.log_m, int(inverse),
+                                          int(coset), FORM_PLAIN))
+        return values
 
     def FFT(self, a):
         return self._run(a, False, False)
