@@ -176,7 +176,8 @@ static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbase
   float best = 1e9f;
   for (int r = 0; r < 3; r++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_accum<F>), dim3(blocks + extra_blocks, 1), dim3(256), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu, 1u, 0u);
+    hipLaunchKernelGGL((k_accum<F>), dim3((unsigned)(lanes / ZG_ACCUM_BLOCK) + extra_blocks, 1), dim3(ZG_ACCUM_BLOCK), 0, 0, du, dw, (uint32_t)lanes, dord, dsorted, db, dpart, 0x7FFFFFFFu, 1u, 0u);
+    if (hipGetLastError() != hipSuccess) printf("{\"error\": \"k_accum launch failed\"}\n");
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -188,7 +189,8 @@ static void run_accum(const char* name, int blocks, uint32_t len, uint32_t nbase
   hipFree(du); hipFree(dord); hipFree(dsorted); hipFree(dw); hipFree(db); hipFree(dpart);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool accum_only = argc > 1;
   F hin[8];
   for (int i = 0; i < 8; i++) {
     hin[i] = F::one();
@@ -219,6 +221,7 @@ int main() {
   hipMalloc(&dclk, sizeof(Clk));
   hipMemcpy(din, hin, sizeof(hin), hipMemcpyHostToDevice);
   hipMemcpy(dp, hp, sizeof(hp), hipMemcpyHostToDevice);
+  if (!accum_only) {
   for (int wps : {1, 2, 3, 4, 6, 8}) run("mul_chain1", k_mul<1>, 256 * wps, 4096, 1.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 2, 3, 4}) run("mul_chain2", k_mul<2>, 256 * wps, 2048, 2.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 2, 3, 6}) run("madd", k_madd, 256 * wps, 512, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
@@ -226,6 +229,7 @@ int main() {
   // sustained load (~100 ms per launch): does the shader clock hold?
   run("madd_straight_desync", k_madd_straight<1>, 512, 512 * 16, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
   run("madd_straight_long", k_madd_straight<0>, 512, 512 * 8, 1.0, dclk, (const Affine<F>*)dp, (XYZZ<F>*)dout);
+  }
   run_accum("k_accum_synth", 512, 512, 1u << 12, dp);
   run_accum("k_accum_synth", 2048, 512, 1u << 12, dp);
   run_accum("k_accum_synth", 2048, 512, 1u << 22, dp);
@@ -235,9 +239,11 @@ int main() {
   run_accum("k_accum_synth_1040_empty_blocks", 2048, 512, 1u << 22, dp, 2, 1040);
   run_accum("k_accum_synth", 2048, 64, 1u << 21, dp, 1);
   run_accum("k_accum_synth", 2048, 64, 1u << 21, dp, 2);
+  if (!accum_only) {
   for (int wps : {1, 3}) run("sub", k_lin<0>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("add", k_lin<1>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("cneg", k_lin<2>, 256 * wps, 2048, 8.0, dclk, (const F*)din, (F*)dout);
   for (int wps : {1, 3}) run("sqr", k_lin<3>, 256 * wps, 512, 8.0, dclk, (const F*)din, (F*)dout);
+  }
   return 0;
 }

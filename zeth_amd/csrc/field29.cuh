@@ -1,0 +1,437 @@
+// Reduced-radix prime-field arithmetic for the bucket-accumulation kernel (gfx950).
+//
+// Why a second representation.  With full 32-bit limbs every 32x32 product fills its 64-bit result, so the sums of a
+// Montgomery product need one carry instruction per multiply (mont_asm.h: 306 instructions for the 136 products of an
+// 8-limb field; v_add_co / v_addc_co issue at the rate of v_mad_u64_u32, profiles/r1_peak_valu.jsonl).  Here an element
+// is NL limbs of B < 32 bits (alt_bn128: 9 x 29, BLS12-377 Fq: 14 x 28) held in 32-bit registers.  A product of two
+// limbs is 2B bits, so a 64-bit accumulator takes a whole column of the schoolbook product -- 2 NL products -- through
+// v_mad_u64_u32's own 64-bit addend with no carry instruction at all; carries move once per column (one shift).
+// Additions and subtractions are limb-wise with no carry chain either: limbs may grow past B bits ("lazy" values) and
+// are brought back by a carry pass only where the next use needs it.
+//
+// Montgomery radix R' = 2^(NL B) (2^261, 2^392): R'/p is 169 (alt_bn128) and 38,996 (BLS12-377), so a product of any
+// two values below about 13 p is again below 2 p and NO conditional subtraction is ever needed inside the kernel.
+//
+// Safety is checked by the compiler: a value's type E<K, VB, LMAX> carries VB (the value is < VB * p) and LMAX (every
+// limb is <= LMAX); every operation static_asserts that its column sums stay below 2^64, its limbs below 2^32 and its
+// operands within the Montgomery bound, and computes the bounds of its result.  Formulas are written with `auto`.
+//
+// Stored data stays in the library's one format (32-bit limbs, R = 2^(32 N): libff's mont_repr).  unpack() reads such an
+// element shifted left by SHIFT = NL B - 32 N bits, which multiplies it by R'/R: the stored residue x R becomes x R'
+// (below 2^SHIFT p) for free.  pack() multiplies by R mod p the Montgomery way (x R' -> x R), reduces to [0, p) and
+// writes 32-bit limbs.
+//
+// Replaces (inside k_accum only) the same libff Fp_model arithmetic field.cuh restates; results are the same field
+// elements, so every MSM output stays bit-identical (tests/test_gpu_msm*.py, tests/test_field29.py).
+#pragma once
+#include <stdint.h>
+
+#include "field.cuh"
+
+namespace zg {
+
+// Parameters of the reduced-radix form of field P (curve_constants.h): limb count and width
+template <class P>
+struct Radix;
+template <>
+struct Radix<Bn254FqParams> {
+  static constexpr int NL = 9, B = 29;
+};
+template <>
+struct Radix<Bls377FqParams> {
+  static constexpr int NL = 14, B = 28;
+};
+
+template <class P>
+struct K29 {
+  using Params = P;
+  static constexpr int N = P::N;  // 32-bit limbs of the stored form
+  static constexpr int NL = Radix<P>::NL, B = Radix<P>::B;
+  static constexpr int SHIFT = NL * B - 32 * N;
+  static constexpr uint32_t MASK = (1u << B) - 1u;
+  static constexpr uint64_t LNORM = MASK;  // limb bound of a normalised value
+  static_assert(SHIFT >= 0 && SHIFT < B, "radix does not cover the stored form");
+
+  struct Limbs {
+    uint32_t v[NL];
+  };
+  // k * p in radix 2^B (k small)
+  static constexpr Limbs times_p(uint64_t k) {
+    Limbs r{};
+    // p as a bit string from its 32-bit limbs
+    unsigned __int128 carry = 0;
+    for (int i = 0; i < NL; i++) {
+      // limb i of p
+      uint64_t limb = 0;
+      const int bit0 = i * B;
+      for (int b = 0; b < B; b++) {
+        const int bit = bit0 + b;
+        if (bit < 32 * N && ((P::P[bit / 32] >> (bit % 32)) & 1u)) limb |= 1ull << b;
+      }
+      const unsigned __int128 t = (unsigned __int128)limb * k + carry;
+      r.v[i] = (uint32_t)((uint64_t)t & MASK);
+      carry = t >> B;
+    }
+    r.v[NL - 1] += (uint32_t)((uint64_t)carry << B);  // the top limb takes what is left (k p < 2^(NL B) for the k used)
+    return r;
+  }
+  static constexpr Limbs PL = times_p(1);
+  // -p^-1 mod 2^B from -p^-1 mod 2^32
+  static constexpr uint32_t INV = P::INV & MASK;
+  static constexpr uint64_t top_of_p() { return PL.v[NL - 1]; }  // p >> (B (NL - 1))
+  // floor(R' / p) - 1, conservatively from the top limb: p >= top * 2^(B (NL-1)), R' = 2^B * 2^(B (NL-1))
+  static constexpr uint64_t mont_room() { return ((1ull << B) / (top_of_p() + 1)) - 1; }
+
+  // does a column of the product fit 64 bits?  NL products of limbs (a top limb is bounded by the value: < V (p_top + 1))
+  // + NL products m_i p_j + the carry from the column below
+  static constexpr bool column_fits(uint64_t va, uint64_t la, uint64_t vb, uint64_t lb) {
+    const uint64_t ta = va * (top_of_p() + 1), tb = vb * (top_of_p() + 1);
+    const unsigned __int128 ea = la > ta ? la : ta, eb = lb > tb ? lb : tb;
+    return (unsigned __int128)NL * ea * eb + (unsigned __int128)NL * LNORM * LNORM + ((unsigned __int128)1 << (64 - B)) <
+           ((unsigned __int128)1 << 64);
+  }
+
+  // k p in the redundant form used by sub(): every limb below the top raised by c 2^B - c (limb 0 by c 2^B) against c
+  // borrowed from the limb above, so that z_i >= c (2^B - 1) + (digit i of k p) for i < NL - 1
+  static constexpr Limbs sub_const(uint64_t k, uint64_t c) {
+    Limbs z = times_p(k);
+    for (int i = 0; i < NL - 1; i++) z.v[i] += (uint32_t)(c << B) - (i ? (uint32_t)c : 0u);
+    z.v[NL - 1] -= (uint32_t)c;
+    return z;
+  }
+  // The constant for subtracting a value < vb p with limbs <= lb: the smallest (c, k) with every lower limb of
+  // sub_const(k, c) >= lb and k >= vb + 1 (then its top limb covers the subtrahend's: (k - vb) p_top > c).  A limb bound
+  // a few units above c (2^B - 1) -- the trace of a carry pass -- is met by the digits of k p themselves.
+  struct SubPlan {
+    uint64_t k, c;
+  };
+  static constexpr bool sub_const_covers(uint64_t k, uint64_t c, uint64_t lb) {
+    const Limbs z = sub_const(k, c);
+    for (int i = 0; i < NL - 1; i++)
+      if (z.v[i] < lb) return false;
+    return true;
+  }
+  static constexpr SubPlan sub_plan(uint64_t vb, uint64_t lb) {
+    uint64_t c = lb / LNORM;
+    if (c == 0) c = 1;
+    for (;; c++)
+      for (uint64_t k = vb + 1; k < vb + 5; k++)
+        if (sub_const_covers(k, c, lb)) return SubPlan{k, c};
+  }
+};
+template <class P>
+constexpr typename K29<P>::Limbs K29<P>::PL;
+
+// value < VB p, every limb <= LMAX
+template <class P, uint64_t VB, uint64_t LMAX>
+struct E29 {
+  using K = K29<P>;
+  static constexpr uint64_t vb = VB, lmax = LMAX;
+  uint32_t v[K::NL];
+};
+
+namespace f29 {
+
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
+ZG_HD auto add(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
+  using K = K29<P>;
+  static_assert(LA + LB < (1ull << 32), "add: limb overflow");
+  E29<P, VA + VB, LA + LB> r;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD auto dbl(const E29<P, VA, LA>& a) {
+  using K = K29<P>;
+  static_assert(2 * LA < (1ull << 32), "dbl: limb overflow");
+  E29<P, 2 * VA, 2 * LA> r;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) r.v[i] = a.v[i] << 1;
+  return r;
+}
+
+// a - b + k p >= 0 limb by limb (k p in a redundant form whose limbs cover b's: K29::sub_plan)
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
+ZG_HD auto sub(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
+  using K = K29<P>;
+  constexpr typename K::SubPlan plan = K::sub_plan(VB, LB);
+  constexpr uint64_t c = plan.c, k = plan.k;
+  constexpr uint64_t zmax = K::LNORM + (c << K::B);
+  static_assert(LA + zmax < (1ull << 32), "sub: limb overflow");
+  static_assert((k + VA) * (K::top_of_p() + 1) + c < (1ull << 32), "sub: top limb overflow");
+  static_assert(K::top_of_p() > c + 1, "sub: top limb of p too small to lend");
+  constexpr typename K::Limbs z = K::sub_const(k, c);
+  E29<P, VA + k, LA + zmax> r;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) r.v[i] = a.v[i] + z.v[i] - b.v[i];
+  return r;
+}
+
+// k p - a  (a lazily negated value; same bounds as sub from zero)
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD auto neg(const E29<P, VA, LA>& a) {
+  E29<P, 0, 0> z;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) z.v[i] = 0;
+  return sub(z, a);
+}
+
+// one parallel carry pass: limbs come back to <= 2^B - 1 + (LMAX >> B); the value is unchanged
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD auto carry(const E29<P, VA, LA>& a) {
+  using K = K29<P>;
+  E29<P, VA, K::LNORM + (LA >> K::B)> r;
+  r.v[0] = a.v[0] & K::MASK;
+#pragma unroll
+  for (int i = 1; i < K::NL - 1; i++) r.v[i] = (a.v[i] & K::MASK) + (a.v[i - 1] >> K::B);
+  r.v[K::NL - 1] = a.v[K::NL - 1] + (a.v[K::NL - 2] >> K::B);
+  return r;
+}
+
+// widen the static bounds (to give the two sides of a select one type)
+template <uint64_t VB, uint64_t LB, class P, uint64_t VA, uint64_t LA>
+ZG_HD E29<P, VB, LB> widen(const E29<P, VA, LA>& a) {
+  static_assert(VB >= VA && LB >= LA, "widen: bounds may only grow");
+  E29<P, VB, LB> r;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) r.v[i] = a.v[i];
+  return r;
+}
+
+// flag ? b : a, limb-wise through a mask (v_bfi_b32; v_cndmask_b32 on vcc is five times slower on gfx950)
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD E29<P, VA, LA> select(const E29<P, VA, LA>& a, const E29<P, VA, LA>& b, bool flag) {
+  const uint32_t m = flag ? 0xFFFFFFFFu : 0u;
+  E29<P, VA, LA> r;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) r.v[i] = (b.v[i] & m) | (a.v[i] & ~m);
+  return r;
+}
+
+// Montgomery product a b / R' + (multiple of p), by columns: column k collects a_i b_j and m_i p_j with i + j = k in
+// one 64-bit accumulator, m_k clears its low B bits, the rest moves to column k + 1.  Result < 2 p, limbs normalised.
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  // column sum: NL products of limbs (top limbs are value-bounded and far smaller) + NL products m_i p_j + carry-in
+  static_assert(K::column_fits(VA, LA, VB, LB), "mul: a column overflows 64 bits -- carry() an operand first");
+  static_assert(VA * VB <= K::mont_room(), "mul: operands too large for a result below 2 p");
+  uint32_t m[NL];
+  E29<P, 2, K::LNORM> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) acc += (uint64_t)a.v[i] * b.v[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < NL) acc += (uint64_t)m[i] * K::PL.v[j];
+    }
+    if (k < NL) {
+      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
+      acc += (uint64_t)m[k] * K::PL.v[0];
+    } else {
+      r.v[k - NL] = (uint32_t)acc & K::MASK;
+    }
+    acc >>= B;
+  }
+  r.v[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// a^2: the cross products once, against the doubled operand
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD E29<P, 2, K29<P>::LNORM> sqr(const E29<P, VA, LA>& a) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  static_assert(K::column_fits(VA, LA, VA, LA), "sqr: a column overflows 64 bits -- carry() the operand first");
+  static_assert(VA * VA <= K::mont_room(), "sqr: operand too large for a result below 2 p");
+  static_assert(2 * LA < (1ull << 32), "sqr: doubled limb overflow");
+  uint32_t m[NL], a2[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
+  E29<P, 2, K::LNORM> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j > i && j < NL) acc += (uint64_t)a2[i] * a.v[j];
+      if (j == i) acc += (uint64_t)a.v[i] * a.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < NL) acc += (uint64_t)m[i] * K::PL.v[j];
+    }
+    if (k < NL) {
+      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
+      acc += (uint64_t)m[k] * K::PL.v[0];
+    } else {
+      r.v[k - NL] = (uint32_t)acc & K::MASK;
+    }
+    acc >>= B;
+  }
+  r.v[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// ---- conversions to and from the stored form (32-bit limbs, Montgomery R = 2^(32 N)) ----------------------------
+// stored x R  ->  x R' = (x R) 2^SHIFT, read as limbs of the shifted bit string; value < 2^SHIFT p, limbs normalised
+template <class P>
+ZG_HD E29<P, (1ull << K29<P>::SHIFT), K29<P>::LNORM> unpack(const Fp<P>& s) {
+  using K = K29<P>;
+  E29<P, (1ull << K::SHIFT), K::LNORM> r;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) {
+    const int bit = i * K::B - K::SHIFT;  // first bit of limb i in the stored integer (negative: zeros shifted in)
+    uint32_t w;
+    if (bit < 0) {
+      w = s.v[0] << (-bit);
+    } else {
+      const int q = bit / 32, sh = bit % 32;
+      const uint32_t lo = s.v[q];
+      const uint32_t hi = q + 1 < K::N ? s.v[q + 1] : 0u;
+      w = sh ? (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) : lo;
+    }
+    r.v[i] = w & K::MASK;
+  }
+  return r;
+}
+
+// R mod p (plain; the factor that takes x R' back to x R through mul()) and R' mod p (the Montgomery one of this form)
+// as normalised limbs
+template <class P>
+struct Consts29 {
+  using K = K29<P>;
+  static constexpr typename K::Limbs from_words(const uint32_t* w) {
+    typename K::Limbs r{};
+    for (int i = 0; i < K::NL; i++) {
+      uint64_t limb = 0;
+      for (int b = 0; b < K::B; b++) {
+        const int bit = i * K::B + b;
+        if (bit < 32 * K::N && ((w[bit / 32] >> (bit % 32)) & 1u)) limb |= 1ull << b;
+      }
+      r.v[i] = (uint32_t)limb;
+    }
+    return r;
+  }
+  // 2 a mod p for a < p (normalised limbs)
+  static constexpr typename K::Limbs dbl_mod_p(typename K::Limbs a) {
+    typename K::Limbs d{}, e{};
+    uint32_t cy = 0;
+    for (int i = 0; i < K::NL; i++) {
+      const uint32_t t = (a.v[i] << 1) + cy;
+      d.v[i] = i < K::NL - 1 ? (t & K::MASK) : t;
+      cy = i < K::NL - 1 ? (t >> K::B) : 0;
+    }
+    int64_t br = 0;
+    for (int i = 0; i < K::NL; i++) {
+      const int64_t x = (int64_t)d.v[i] - (int64_t)K::PL.v[i] + br;
+      if (i < K::NL - 1) {
+        e.v[i] = (uint32_t)((uint64_t)x & K::MASK);
+        br = x < 0 ? -1 : 0;
+      } else {
+        e.v[i] = (uint32_t)x;
+        br = x < 0 ? -1 : 0;
+      }
+    }
+    return br ? d : e;
+  }
+  static constexpr typename K::Limbs one_prime() {
+    typename K::Limbs r = from_words(P::R1);
+    for (int i = 0; i < K::SHIFT; i++) r = dbl_mod_p(r);
+    return r;
+  }
+  static constexpr typename K::Limbs R_MOD_P = from_words(P::R1);
+  static constexpr typename K::Limbs ONE_PRIME = one_prime();
+};
+template <class P>
+constexpr typename K29<P>::Limbs Consts29<P>::R_MOD_P;
+template <class P>
+constexpr typename K29<P>::Limbs Consts29<P>::ONE_PRIME;
+
+// R mod p (plain integer): mul(x R', this) = x R
+template <class P>
+ZG_HD E29<P, 1, K29<P>::LNORM> r_conv() {
+  E29<P, 1, K29<P>::LNORM> r;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) r.v[i] = Consts29<P>::R_MOD_P.v[i];
+  return r;
+}
+// R' mod p: the Montgomery one of this form; mul(v, one()) = v brought below 2 p
+template <class P>
+ZG_HD E29<P, 1, K29<P>::LNORM> one() {
+  E29<P, 1, K29<P>::LNORM> r;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) r.v[i] = Consts29<P>::ONE_PRIME.v[i];
+  return r;
+}
+template <class P>
+ZG_HD E29<P, 0, 0> zero() {
+  E29<P, 0, 0> r;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) r.v[i] = 0;
+  return r;
+}
+
+// x R' (any value the Montgomery bound admits against 1 p) -> stored x R in [0, p)
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD Fp<P> pack(const E29<P, VA, LA>& a) {
+  using K = K29<P>;
+  const auto t = mul(a, r_conv<P>());  // < 2 p, normalised
+  // d = t - p with a borrow chain on B-bit limbs; keep t when it borrows
+  uint32_t d[K::NL];
+  int32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) {
+    const int32_t x = (int32_t)t.v[i] - (int32_t)K::PL.v[i] + br;
+    if (i < K::NL - 1) {
+      d[i] = (uint32_t)x & K::MASK;
+      br = x >> K::B;  // 0 or -1
+    } else {
+      d[i] = (uint32_t)x;
+      br = x >> 31;
+    }
+  }
+  const uint32_t keep = (uint32_t)br;  // all ones when t < p
+  uint32_t l[K::NL + 1];
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) l[i] = (t.v[i] & keep) | (d[i] & ~keep);
+  l[K::NL] = 0;
+  Fp<P> r;
+#pragma unroll
+  for (int j = 0; j < K::N; j++) {
+    const int bit = 32 * j;
+    const int q = bit / K::B, sh = bit % K::B;
+    uint64_t w = (uint64_t)l[q] >> sh;
+    if (q + 1 <= K::NL) w |= (uint64_t)l[q + 1] << (K::B - sh);
+    if (q + 2 <= K::NL && 2 * K::B - sh < 32) w |= (uint64_t)l[q + 2] << (2 * K::B - sh);
+    r.v[j] = (uint32_t)w;
+  }
+  return r;
+}
+
+// value (< 2 p, normalised limbs) congruent to zero?  i.e. equal to 0 or to p
+template <class P>
+ZG_HD bool is_zero_mod_p(const E29<P, 2, K29<P>::LNORM>& a) {
+  using K = K29<P>;
+  uint32_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) {
+    z |= a.v[i];
+    e |= a.v[i] ^ K::PL.v[i];
+  }
+  return z == 0 || e == 0;
+}
+
+}  // namespace f29
+}  // namespace zg

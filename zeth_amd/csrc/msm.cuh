@@ -25,6 +25,7 @@
 
 #include <vector>
 
+#include "accum29.cuh"
 #include "curve.cuh"
 
 namespace zg {
@@ -724,6 +725,19 @@ __device__ __forceinline__ void xyzz_madd_wave(XYZZ<F>& acc, const Affine<F>& p)
   acc.zzz = F::mul(acc.zzz, PPP);
 }
 
+// which coordinate fields accumulate in the reduced-radix form (G1 of both curves; G2 keeps the 32-bit-limb path)
+#ifndef ZG_ACCUM_RADIX29
+#define ZG_ACCUM_RADIX29 1
+#endif
+template <class F>
+struct Radix29For {
+  static constexpr bool value = false;
+};
+template <class P>
+struct Radix29For<Fp<P>> {
+  static constexpr bool value = ZG_ACCUM_RADIX29 != 0;
+};
+
 #ifndef ZG_ACCUM_MIN_WAVES
 #define ZG_ACCUM_MIN_WAVES 1
 #endif
@@ -753,21 +767,39 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
   uint32_t e = ent[0];
   uint32_t en = ent[last < 1 ? last : 1];
   Affine<F> p = load_affine(bases, e & idx_mask);
-  p.y = F::cneg(p.y, (e >> 31) != 0);
-  XYZZ<F> acc = XYZZ<F>::from_affine(p);
-  p = load_affine(bases, en & idx_mask);
-  e = en;
-  en = ent[last < 2 ? last : 2];
-  for (uint32_t t = 1; t <= last; t++) {
-    const Affine<F> pn = load_affine(bases, en & idx_mask);
-    const uint32_t en2 = ent[t + 2 <= last ? t + 2 : last];
-    p.y = F::cneg(p.y, (e >> 31) != 0);
-    xyzz_madd_wave(acc, p);
+  if constexpr (Radix29For<F>::value) {
+    // G1: the accumulator lives in the reduced-radix form (accum29.cuh) and returns to the stored form once per unit
+    using P = typename F::Params;
+    Acc29<P> acc = acc29_from_affine<P>(p, (e >> 31) != 0);
+    p = load_affine(bases, en & idx_mask);
     e = en;
-    en = en2;
-    p = pn;
+    en = ent[last < 2 ? last : 2];
+    for (uint32_t t = 1; t <= last; t++) {
+      const Affine<F> pn = load_affine(bases, en & idx_mask);
+      const uint32_t en2 = ent[t + 2 <= last ? t + 2 : last];
+      acc = madd29<P>(acc, p, (e >> 31) != 0);
+      e = en;
+      en = en2;
+      p = pn;
+    }
+    part[u] = acc29_to_xyzz<P>(acc);
+  } else {
+    p.y = F::cneg(p.y, (e >> 31) != 0);
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+    p = load_affine(bases, en & idx_mask);
+    e = en;
+    en = ent[last < 2 ? last : 2];
+    for (uint32_t t = 1; t <= last; t++) {
+      const Affine<F> pn = load_affine(bases, en & idx_mask);
+      const uint32_t en2 = ent[t + 2 <= last ? t + 2 : last];
+      p.y = F::cneg(p.y, (e >> 31) != 0);
+      xyzz_madd_wave(acc, p);
+      e = en;
+      en = en2;
+      p = pn;
+    }
+    part[u] = acc;
   }
-  part[u] = acc;
 }
 
 // Buckets that were split into several units (skewed scalars: 0/1-heavy witnesses, short top windows) are folded into
