@@ -132,6 +132,30 @@ struct E29 {
 
 namespace f29 {
 
+#ifndef ZG_F29_ASM
+#define ZG_F29_ASM 1
+#endif
+// acc += a * b in ONE v_mad_u64_u32 on the accumulator itself.  Written as an instruction because the compiler, given
+// `acc += a * b` twice, splits a column over two accumulators and joins them with a 64-bit add per column (162 extra
+// v_lshl_add_u64 per mixed addition); one chain per column is enough with two or more waves on a SIMD.
+ZG_HD void mac(uint64_t& acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM
+  uint64_t carry_out;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_out) : "v"(a), "v"(b));
+#else
+  acc += (uint64_t)a * b;
+#endif
+}
+// the same with a compile-time constant factor (a limb of p), held in a scalar register
+ZG_HD void mac_const(uint64_t& acc, uint32_t a, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM
+  uint64_t carry_out;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_out) : "v"(a), "s"(k));
+#else
+  acc += (uint64_t)a * k;
+#endif
+}
+
 template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
 ZG_HD auto add(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
   using K = K29<P>;
@@ -227,16 +251,16 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul(const E29<P, VA, LA>& a, const E29<P, VB, LB>
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
-      if (j >= 0 && j < NL) acc += (uint64_t)a.v[i] * b.v[j];
+      if (j >= 0 && j < NL) mac(acc, a.v[i], b.v[j]);
     }
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
-      if (i < k && j >= 1 && j < NL) acc += (uint64_t)m[i] * K::PL.v[j];
+      if (i < k && j >= 1 && j < NL) mac_const(acc, m[i], K::PL.v[j]);
     }
     if (k < NL) {
       m[k] = ((uint32_t)acc * K::INV) & K::MASK;
-      acc += (uint64_t)m[k] * K::PL.v[0];
+      mac_const(acc, m[k], K::PL.v[0]);
     } else {
       r.v[k - NL] = (uint32_t)acc & K::MASK;
     }
@@ -264,17 +288,17 @@ ZG_HD E29<P, 2, K29<P>::LNORM> sqr(const E29<P, VA, LA>& a) {
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
-      if (j > i && j < NL) acc += (uint64_t)a2[i] * a.v[j];
-      if (j == i) acc += (uint64_t)a.v[i] * a.v[i];
+      if (j > i && j < NL) mac(acc, a2[i], a.v[j]);
+      if (j == i) mac(acc, a.v[i], a.v[i]);
     }
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
-      if (i < k && j >= 1 && j < NL) acc += (uint64_t)m[i] * K::PL.v[j];
+      if (i < k && j >= 1 && j < NL) mac_const(acc, m[i], K::PL.v[j]);
     }
     if (k < NL) {
       m[k] = ((uint32_t)acc * K::INV) & K::MASK;
-      acc += (uint64_t)m[k] * K::PL.v[0];
+      mac_const(acc, m[k], K::PL.v[0]);
     } else {
       r.v[k - NL] = (uint32_t)acc & K::MASK;
     }

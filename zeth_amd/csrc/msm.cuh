@@ -738,6 +738,12 @@ struct Radix29For<Fp<P>> {
   static constexpr bool value = ZG_ACCUM_RADIX29 != 0;
 };
 
+#ifndef ZG_ACCUM_TOUCH
+#define ZG_ACCUM_TOUCH 0
+#endif
+#ifndef ZG_ACCUM_PIN_LOADS
+#define ZG_ACCUM_PIN_LOADS 0
+#endif
 #ifndef ZG_ACCUM_MIN_WAVES
 #define ZG_ACCUM_MIN_WAVES 1
 #endif
@@ -774,13 +780,27 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
     p = load_affine(bases, en & idx_mask);
     e = en;
     en = ent[last < 2 ? last : 2];
+#if ZG_ACCUM_TOUCH
+    uint32_t touch_prev = 0;
+#endif
     for (uint32_t t = 1; t <= last; t++) {
       const Affine<F> pn = load_affine(bases, en & idx_mask);
       const uint32_t en2 = ent[t + 2 <= last ? t + 2 : last];
+#if ZG_ACCUM_TOUCH
+      // one word of the base after next: brings its line (and its page translation) in a whole addition early
+      const uint32_t touch = reinterpret_cast<const uint32_t*>(bases + (en2 & idx_mask))[0];
+#endif
+#if ZG_ACCUM_PIN_LOADS
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       acc = madd29<P>(acc, p, (e >> 31) != 0);
       e = en;
       en = en2;
       p = pn;
+#if ZG_ACCUM_TOUCH
+      asm volatile("" ::"v"(touch_prev));
+      touch_prev = touch;
+#endif
     }
     part[u] = acc29_to_xyzz<P>(acc);
   } else {
