@@ -156,8 +156,9 @@ typedef struct {
 /* Uploads the proving key once (bases to HBM in Montgomery affine form, constraint matrices as CSR) and allocates
  * the per-proof device scratch: the analogue of loading the keypair before proving (zeth_tool/prove_cmd.cpp:39-43,
  * prover_server/prover_server.cpp:449-493).  Size mismatches -> ZG_ERR_INVALID_ARGUMENT.
- * An H query of 2^18 points or more is kept as a fixed-base table (see zg_bases_precompute; 12-13 times its memory);
- * the environment variable ZG_PK_TABLE_MIN sets another threshold (0 = never). */
+ * The H query of a key whose domain has 2^18 points or more is kept as a fixed-base table (see zg_bases_precompute;
+ * 12-13 times its memory; when that memory cannot be had the plain query is used); the environment variable
+ * ZG_PK_TABLE_MIN sets another domain-size threshold (0 = never). */
 int zg_pk_create(zg_ctx* ctx, int curve, const zg_pk_view* view, zg_pk** out);
 void zg_pk_free(zg_pk* pk);
 /* A second prover over the same resident key, for another calling thread: it shares the key's bases and matrices

@@ -29,6 +29,43 @@ def main():
     print(json.dumps(measure(args)), flush=True)
 
 
+def cpu_prove(cid, cs, extra, primary, aux, rb, sb, threads):
+    """The CPU oracle's proof (oracle/zeth_cpu.cpp, oz_prove) on the key material generate_setup_from_secrets returned
+    with return_scalars=True: (proof bytes in the C ABI's plain layout, [witness map s, MSM s, total s])."""
+    import numpy as np
+
+    import cpu_oracle
+    import zeth_amd.lib as zl
+
+    cpu_oracle.lib().oz_set_threads(threads)
+    keep = []
+
+    def vp(b):
+        cb = ctypes.create_string_buffer(b, max(1, len(b)))
+        keep.append(cb)
+        return ctypes.cast(cb, ctypes.c_void_p)
+
+    pl = extra["plain"]
+    pts = extra["points"]
+    views = []
+    for k in range(3):
+        vals = b"".join(v.to_bytes(32, "little") for v in cs.val[k])
+        views.append(cpu_oracle.CsrView(cs.row_ptr[k].ctypes.data, cs.col[k].ctypes.data, vp(vals)))
+    views = (cpu_oracle.CsrView * 3)(*views)
+    bidx = np.array(extra["b_idx"], dtype=np.uint32)
+    enc = lambda g, P: vp(cpu_oracle.enc_point(cid, g, P))  # noqa: E731
+    view = cpu_oracle.PkView(enc(1, pts[0]), enc(1, pts[1]), enc(2, pts[2]), enc(1, pts[3]), enc(2, pts[4]),
+                             vp(pl["A"]), cs.num_variables + 1, bidx.ctypes.data, vp(pl["B2"]), vp(pl["B1"]), len(bidx),
+                             vp(pl["H"]), cs.domain_size() - 1, vp(pl["L"]), cs.num_variables - cs.num_inputs)
+    full = vp(zl.encode_scalars(primary) + zl.encode_scalars(aux))
+    cout = ctypes.create_string_buffer(8 * zl.fq_bytes(cid))
+    sec = (ctypes.c_double * 3)()
+    rc = cpu_oracle.lib().oz_prove(cid, ctypes.byref(view), cs.num_inputs, cs.num_variables, cs.num_constraints, views,
+                                   full, rb, sb, threads, cout, sec)
+    assert rc == 0
+    return cout.raw, [sec[0], sec[1], sec[2]]
+
+
 def measure(args, ctx=None):
     import zeth_amd
     import zeth_amd.lib as zl
@@ -124,39 +161,13 @@ def measure(args, ctx=None):
     if not args.no_cpu:
         import cpu_oracle
 
-        threads = min(16, cpu_oracle.max_threads())
-        cpu_oracle.lib().oz_set_threads(threads)
-        keep = []
-
-        def vp(b):
-            cb = ctypes.create_string_buffer(b, max(1, len(b)))
-            keep.append(cb)
-            return ctypes.cast(cb, ctypes.c_void_p)
-
-        pl = extra["plain"]
-        pts = extra["points"]
-        views = []
-        for k in range(3):
-            vals = b"".join(v.to_bytes(32, "little") for v in cs.val[k])
-            views.append(cpu_oracle.CsrView(cs.row_ptr[k].ctypes.data, cs.col[k].ctypes.data, vp(vals)))
-        views = (cpu_oracle.CsrView * 3)(*views)
-        import numpy as np
-
-        bidx = np.array(extra["b_idx"], dtype=np.uint32)
-        enc = lambda g, P: vp(cpu_oracle.enc_point(cid, g, P))  # noqa: E731
-        view = cpu_oracle.PkView(enc(1, pts[0]), enc(1, pts[1]), enc(2, pts[2]), enc(1, pts[3]), enc(2, pts[4]),
-                                 vp(pl["A"]), cs.num_variables + 1, bidx.ctypes.data, vp(pl["B2"]), vp(pl["B1"]), len(bidx),
-                                 vp(pl["H"]), cs.domain_size() - 1, vp(pl["L"]), cs.num_variables - cs.num_inputs)
-        full = vp(zl.encode_scalars(primary) + zl.encode_scalars(aux))
-        cout = ctypes.create_string_buffer(8 * n)
-        sec = (ctypes.c_double * 3)()
-        rc = cpu_oracle.lib().oz_prove(cid, ctypes.byref(view), cs.num_inputs, cs.num_variables, cs.num_constraints, views,
-                                       full, rb, sb, threads, cout, sec)
-        assert rc == 0
-        res["bit_exact_vs_cpu_oracle"] = cout.raw == raw
+        threads = cpu_oracle.max_threads()
+        cpu_raw, sec = cpu_prove(cid, cs, extra, primary, aux, rb, sb, threads)
+        res["bit_exact_vs_cpu_oracle"] = cpu_raw == raw
         res["cpu_baseline"] = {"ms_per_proof": sec[2] * 1e3, "witness_map_ms": sec[0] * 1e3, "msm_ms": sec[1] * 1e3,
                                "cores": threads, "kind": "port",
-                               "note": "C++ restatement of the libsnark prover (BDLO12 multi_exp with 0/1 filter, OpenMP)"}
+                               "note": "C++ restatement of the libsnark prover (BDLO12 multi_exp with 0/1 filter, OpenMP), "
+                                       "all host cores"}
         res["speedup_vs_cpu"] = sec[2] / times[len(times) // 2]
     if not args.no_verify:
         from zeth_model import BLS12_377, BN254, VerificationKey, verify

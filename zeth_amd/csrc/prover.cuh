@@ -161,6 +161,7 @@ struct ProvingKeyDev : PkBase {
     for (int k = 0; k < 3; k++) {
       if (nc && (!src[k]->row_ptr || src[k]->row_ptr[0] != 0)) return ZG_ERR_INVALID_ARGUMENT;
       size_t nnz = nc ? (size_t)src[k]->row_ptr[nc] : 0;
+      if (nnz && (!src[k]->col || !src[k]->val)) return ZG_ERR_INVALID_ARGUMENT;
       for (size_t i = 0; i < nc; i++)
         if (src[k]->row_ptr[i] > src[k]->row_ptr[i + 1]) return ZG_ERR_INVALID_ARGUMENT;
       for (size_t t = 0; t < nnz; t++)
@@ -192,26 +193,31 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(up1(&H, v->H_query, v->H_len));
     ZG_TRY(up1(&L, v->L_query, v->L_len));
     {
-      // ZG_PK_TABLE_MIN: smallest H query that gets a table (default 2^18 points: a JoinSplit-scale proof, H of 2^19 - 1
+      // ZG_PK_TABLE_MIN: smallest domain whose H query gets a table (default 2^18, i.e. 2^18 - 1 points: a JoinSplit-scale proof, H of 2^19 - 1
       // points, takes 5.15 ms with it and 5.5 ms without; 0 = never)
       const char* e = getenv("ZG_PK_TABLE_MIN");
       const size_t table_min = e ? strtoull(e, nullptr, 0) : ((size_t)1 << 18);
-      if (table_min && v->H_len >= table_min && v->H_len >= 1024) {
+      if (table_min && v->H_len + 1 >= table_min && v->H_len >= 1024) {  // H_len = domain size - 1
         int c = 0, D = 0;
         ZG_TRY(o1->table_params(v->H_len, 0, &c, &D));
         if ((uint64_t)D * v->H_len < (1ull << 31)) {
           Affine<Fq>* table = nullptr;
-          ZG_HIP(hipMalloc((void**)&table, (size_t)D * v->H_len * sizeof(Affine<Fq>)));
-          ZG_HIP(hipMemcpyAsync(table, H, v->H_len * sizeof(Affine<Fq>), hipMemcpyDeviceToDevice, st));
-          int s = o1->table_build(ctx, table, v->H_len, c, D);
-          if (s != ZG_OK) {
-            hipFree(table);
-            return s;
+          if (hipMalloc((void**)&table, (size_t)D * v->H_len * sizeof(Affine<Fq>)) != hipSuccess) {
+            (void)hipGetLastError();  // no room for the table: the plain H query is resident and proves just as well
+            table = nullptr;
           }
-          hipFree(H);
-          H = table;
-          H_c = c;
-          H_levels = D;
+          if (table) {
+            ZG_HIP(hipMemcpyAsync(table, H, v->H_len * sizeof(Affine<Fq>), hipMemcpyDeviceToDevice, st));
+            int s = o1->table_build(ctx, table, v->H_len, c, D);
+            if (s != ZG_OK) {
+              hipFree(table);
+              return s;
+            }
+            hipFree(H);
+            H = table;
+            H_c = c;
+            H_levels = D;
+          }
         }
       }
     }
