@@ -37,7 +37,9 @@ def cpu_baseline(bases, scalars_dev, sample_n):
     import cpu_oracle
     import zeth_amd.lib as zl
 
-    threads = min(16, cpu_oracle.max_threads())
+    # every thread OpenMP gives this process: omp_get_max_threads(), what libsnark's MULTICORE build uses for its
+    # chunks.  On the GPU box OMP_NUM_THREADS is the job's CPU share (16 of a machine whose nproc is many times that).
+    threads = cpu_oracle.max_threads()
     cpu_oracle.lib().oz_set_threads(threads)
     ab = 64
     buf = ctypes.create_string_buffer(sample_n * ab)
@@ -54,7 +56,60 @@ def cpu_baseline(bases, scalars_dev, sample_n):
         "kind": "port",
         "sample": "first 2^%d points of the same bases/scalars, libff-style multi_exp<BDLO12> with %d OpenMP chunks, "
         "%.2f s; result equal to the GPU's on that sample" % (sample_n.bit_length() - 1, threads, sec),
+        "host": host_description(),
+        "build": "oracle/Makefile: -O2 -march=x86-64-v3 -madx -fopenmp (the reference: -O2 -march=native, CMakeLists.txt:197-199; "
+        "native is not usable for a library built in one container and run on another host); portable unsigned __int128 "
+        "limbs, not libff's x86 assembly",
     }
+
+
+def host_description():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+            "sched_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+
+
+def ntt_report(ctx, zeth_amd):
+    """Evaluation-domain transform (BN254 Fr) at the prover's sizes: kernel time from HIP events on the library's stream,
+    as fractions of the HBM roofline (64 m algorithmic bytes per transform) and of the multiply peak."""
+    import ctypes
+
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_ntt.json")))
+    except (OSError, ValueError):
+        pass
+    out = []
+    for lg in (19, 22):
+        m = 1 << lg
+        buf = zeth_amd.DeviceBuffer.random_scalars(ctx, zeth_amd.ALT_BN128, m, 99)
+
+        def run(inv, coset):
+            zeth_amd.lib._check(ctx._L.zg_ntt(ctx._h, 0, ctypes.c_void_p(buf.ptr), lg, inv, coset, zeth_amd.lib.FORM_MONT, 1))
+            return sum(ms for name, ms in ctx.last_timings() if name.startswith("ntt_"))
+
+        run(1, 0)
+        per = {}
+        for inv, coset, name in ((1, 0, "iFFT"), (0, 1, "cosetFFT"), (1, 1, "icosetFFT")):
+            ks = sorted(run(inv, coset) for _ in range(7))
+            per[name] = ks[len(ks) // 2]
+        k_ms = sum(per.values()) / len(per)
+        buf.free()
+        out.append({"log_m": lg, "kernels_ms": k_ms, "per_variant_ms": per,
+                    "hbm": {"algorithmic_bytes": 64 * m, "GBps": 64 * m / (k_ms * 1e-3) / 1e9, "frac": 64 * m / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "mac": {"per_transform": (m // 2) * lg * 136, "frac": (m // 2) * lg * 136 / (k_ms * 1e-3) / PEAK_MAC_PER_S},
+                    "traffic": pmc.get(str(lg))})
+    return {"curve": "alt-bn128 Fr", "transforms": out,
+            "note": "the prover's three variants, mean of their medians; 64 m bytes = one read and one write of the vector "
+            "(SURVEY 8d), (m/2) log2 m butterflies x 136 MAC; traffic = FETCH_SIZE/WRITE_SIZE per transform "
+            "(profiles/r2_pmc_ntt.json, separate rocprofv3 --pmc passes) when collected"}
 
 
 def main():
@@ -67,6 +122,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the JoinSplit-shaped Groth16 prove measurement")
     ap.add_argument("--no-table", action="store_true", help="windowed MSM on the bare bases (no fixed-base table)")
+    ap.add_argument("--no-windowed", action="store_true", help="skip the bare-bases (windowed) leg")
+    ap.add_argument("--no-g2", action="store_true", help="skip the G2 MSM leg")
+    ap.add_argument("--g2-log-n", type=int, default=22)
+    ap.add_argument("--no-ntt", action="store_true", help="skip the evaluation-domain transform report")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +245,79 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(bases, scalars, min(n_local, 1 << args.cpu_log_n))
 
+    def timed_leg(step_fn, steps):
+        """`steps` calls of step_fn between fences, max over ranks: (ms per step, k_accum ms per step, last result)"""
+        res = step_fn()
+        fence()
+        acc = []
+        t_a = time.perf_counter()
+        for _ in range(steps):
+            res = step_fn()
+            acc += [ms for name, ms in ctx.last_timings() if name == "accum"]
+        fence()
+        el = time.perf_counter() - t_a
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el / steps * 1e3, sum(acc) / max(1, len(acc)), res
+
+    # The same job on the BARE bases (no table): what libff::multi_exp computes per call -- 16 signed 16-bit windows.
+    windowed = None
+    if table is not None and not args.no_windowed:
+        bare = zeth_amd.Bases.generate(ctx, zeth_amd.ALT_BN128, zeth_amd.G1, n_local, (t0 + first * d) % C.r, d)
+
+        def step_w():
+            part = bare.msm_bytes(scalars, n_local)
+            return all_gather_sum_bytes(0, 1, part, xdev) if world > 1 else part
+
+        w_ms, w_acc, w_res = timed_leg(step_w, max(3, args.steps // 2))
+        if decode_point(0, 1, w_res) != expect:
+            raise SystemExit("bench.py: windowed MSM result does not match the closed form")
+        bare.free()
+        w_achieved = n_local * 16 * (MAC_PER_POINT_BN254_G1 // 16) / (w_acc * 1e-3)
+        windowed = {"ms_per_step": w_ms, "points_per_s": n_total / (w_ms * 1e-3), "digits_per_scalar": 16,
+                    "roofline": {"kernel": "k_accum", "kernel_ms": w_acc, "achieved": w_achieved / 1e12, "peak": PEAK_MAC_PER_S / 1e12,
+                                 "unit": "TMAC/s", "frac": w_achieved / PEAK_MAC_PER_S},
+                    "verified": "closed form", "note": "bare bases, no precomputed table: the libff::multi_exp equivalent"}
+
+    # BASELINE configs[2]'s second leg: G2 MSM of 2^22 points, sharded by point range like the G1 job
+    g2 = None
+    if not args.no_g2:
+        n2_total = 1 << args.g2_log_n
+        n2 = n2_total // world
+        f2 = rank * n2
+        seed2 = 0x47320000 + (rank << 32)
+        bases2 = zeth_amd.Bases.generate(ctx, zeth_amd.ALT_BN128, zeth_amd.G2, n2, (t0 + f2 * d) % C.r, d)
+        if not args.no_table:
+            bases2.precompute()
+        sc2 = zeth_amd.DeviceBuffer.random_scalars(ctx, zeth_amd.ALT_BN128, n2, seed2)
+
+        def step_g2():
+            part = bases2.msm_bytes(sc2, n2)
+            return all_gather_sum_bytes(0, 2, part, xdev) if world > 1 else part
+
+        g_ms, g_acc, g_res = timed_leg(step_g2, max(3, args.steps // 2))
+        k2 = closed_form_scalar(random_scalars_host(n2, C.r, seed2), (t0 + f2 * d) % C.r, d, C.r)
+        if world > 1:
+            ks2 = [None] * world
+            dist.all_gather_object(ks2, k2)
+            k2 = sum(ks2) % C.r
+        if decode_point(0, 2, g_res) != C.G2.mul(k2, C.G2.gen):
+            raise SystemExit("bench.py: G2 MSM result does not match the closed form")
+        cw2, lv2 = bases2.table_info()
+        g_digits = lv2 if lv2 else 16
+        g_achieved = n2 * g_digits * (65280 // 16) / (g_acc * 1e-3)
+        g2 = {"metric": "bn254_g2_msm_2^%d" % args.g2_log_n, "ms_per_step": g_ms, "points_per_s": n2_total / (g_ms * 1e-3),
+              "fixed_base_table": {"window_bits": cw2, "levels": lv2} if lv2 else None, "verified": "closed form",
+              "roofline": {"kernel": "k_accum (G2)", "kernel_ms": g_acc, "achieved": g_achieved / 1e12, "peak": PEAK_MAC_PER_S / 1e12,
+                           "unit": "TMAC/s", "frac": g_achieved / PEAK_MAC_PER_S,
+                           "note": "4080 MAC per G2 mixed addition (SURVEY 8d: Fq2 product = 3 Fq products)"}}
+        sc2.free()
+        bases2.free()
+
+    ntt = ntt_report(ctx, zeth_amd) if rank == 0 and not args.no_ntt else None
+
     # second headline number (BASELINE.json metric): Groth16 proofs/s on the JoinSplit-shaped circuit, every rank a
     # replica with its own resident key (no collective); outside the timed MSM region above
     prove = None
@@ -219,7 +351,10 @@ def main():
         # inside this process); only quoted for the size they were collected at
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))["kernels"]["k_accum"]
+            pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
+            if not os.path.exists(pmc_path):
+                pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+            pmc = json.load(open(pmc_path))["kernels"]["k_accum"]
             if n_local == 1 << 24 and pmc.get("digits_per_scalar", 16) == digits:
                 traffic = pmc["FETCH_SIZE_bytes_per_launch"] + pmc["WRITE_SIZE_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
@@ -253,7 +388,7 @@ def main():
                 "frac": achieved / PEAK_MAC_PER_S,
                 "kernel_ms": k_ms,
                 "traffic": traffic,
-                "traffic_unit": "bytes per k_accum launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; profiles/r1_pmc_hbm_traffic.json)",
+                "traffic_unit": "bytes per k_accum launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; profiles/r*_pmc_hbm_traffic.json)",
                 "algorithmic_bytes": hbm_bytes,
                 "hbm_algorithmic_GBps": hbm_bytes / (k_ms * 1e-3) / 1e9,
                 "hbm_frac": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -264,6 +399,13 @@ def main():
             },
             "phases_ms": {k2: v / args.steps for k2, v in phase_ms.items()},
         }
+        if windowed is not None:
+            out["windowed"] = windowed
+            out["windowed_ms_per_step"] = windowed["ms_per_step"]
+        if g2 is not None:
+            out["g2_msm"] = g2
+        if ntt is not None:
+            out["ntt"] = ntt
         if prove is not None:
             out["joinsplit_prove"] = prove
         if cpu_base is not None:
