@@ -13,6 +13,7 @@
 #ifndef LIBZETH_GPU_GROTH16_SNARK_HPP
 #define LIBZETH_GPU_GROTH16_SNARK_HPP
 
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -30,17 +31,20 @@ namespace libzeth_gpu
 class device_context
 {
 public:
-    static device_context &get(int device = 0)
+    /// shared ownership: every object that holds device state (keys, bases) keeps its context alive, so the order in
+    /// which statics are destroyed at process exit cannot free a context under a key that still needs it
+    static std::shared_ptr<device_context> get_shared(int device = 0)
     {
         static std::mutex registry_mutex;
-        static std::map<int, std::unique_ptr<device_context>> registry;
+        static std::map<int, std::shared_ptr<device_context>> registry;
         std::lock_guard<std::mutex> lock(registry_mutex);
-        std::unique_ptr<device_context> &slot = registry[device];
+        std::shared_ptr<device_context> &slot = registry[device];
         if (!slot) {
             slot.reset(new device_context(device));
         }
-        return *slot;
+        return slot;
     }
+    static device_context &get(int device = 0) { return *get_shared(device); }
     ~device_context() { zg_ctx_destroy(ctx_); }
     zg_ctx *ctx() const { return ctx_; }
     std::mutex &mutex() { return mutex_; }
@@ -58,7 +62,7 @@ private:
 template<typename ppT> class device_proving_key
 {
 public:
-    device_proving_key(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, int device = 0) : dc_(device_context::get(device)), handle_(nullptr)
+    device_proving_key(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, int device = 0) : dcp_(device_context::get_shared(device)), dc_(*dcp_), handle_(nullptr)
     {
         using FieldT = Fr<ppT>;
         const r1cs_constraint_system<FieldT> &cs = pk.constraint_system;
@@ -167,6 +171,7 @@ public:
     }
 
 private:
+    std::shared_ptr<device_context> dcp_; // keeps the context alive for as long as the key
     device_context &dc_;
     zg_pk *handle_;
 };
@@ -191,13 +196,47 @@ template<typename ppT> Fr<ppT> random_field_element()
 
 namespace internal
 {
-// Device keys built by the stateless entry points, by host key address.  A fingerprint of the key's sizes and of a
-// few of its elements guards against a different key reusing the address.
+// Device keys built by the stateless entry points, by host key address.  A fingerprint over the key's sizes, its
+// single elements, samples of all four queries (B included) and of the constraint system guards against a different
+// or modified key at the same address.  At most MAX_KEYS device keys are kept (least recently used goes first: a
+// device key can hold 12-13 times its H query); release_device_keys() drops them all, and runs by itself at exit while
+// the HIP runtime is still up.
 template<typename ppT> struct device_key_cache {
+    static constexpr size_t MAX_KEYS = 4;
     struct entry {
         uint64_t fingerprint;
+        uint64_t last_use;
         std::shared_ptr<device_proving_key<ppT>> key;
     };
+    struct state {
+        std::mutex m;
+        std::map<const void *, entry> cache;
+        uint64_t clock = 0;
+        bool exit_hook = false;
+    };
+    static state &st()
+    {
+        static state *s = new state(); // never destroyed: nothing of it runs inside static destructors
+        return *s;
+    }
+    template<typename T> static void mix_samples(uint64_t &h, const std::vector<T> &v)
+    {
+        auto mix = [&h](const void *p, size_t n) {
+            const uint8_t *b = (const uint8_t *)p;
+            for (size_t i = 0; i < n; i++) {
+                h = (h ^ b[i]) * 0x100000001b3ull;
+            }
+        };
+        const size_t n = v.size();
+        mix(&n, sizeof(n));
+        const size_t step = n / 61 + 1; // up to ~61 evenly spaced elements, always the first and the last
+        for (size_t i = 0; i < n; i += step) {
+            mix(&v[i], sizeof(T));
+        }
+        if (n) {
+            mix(&v[n - 1], sizeof(T));
+        }
+    }
     static uint64_t fingerprint(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
     {
         uint64_t h = 0xcbf29ce484222325ull;
@@ -207,43 +246,75 @@ template<typename ppT> struct device_key_cache {
                 h = (h ^ b[i]) * 0x100000001b3ull;
             }
         };
-        const size_t sizes[6] = {pk.A_query.size(),
-                                 pk.B_query.values.size(),
-                                 pk.H_query.size(),
-                                 pk.L_query.size(),
-                                 pk.constraint_system.num_constraints(),
-                                 pk.constraint_system.num_variables()};
-        mix(sizes, sizeof(sizes));
         mix(&pk.alpha_g1, sizeof(pk.alpha_g1));
+        mix(&pk.beta_g1, sizeof(pk.beta_g1));
+        mix(&pk.beta_g2, sizeof(pk.beta_g2));
         mix(&pk.delta_g1, sizeof(pk.delta_g1));
-        if (!pk.A_query.empty()) {
-            mix(&pk.A_query.front(), sizeof(G1<ppT>));
-            mix(&pk.A_query.back(), sizeof(G1<ppT>));
-        }
-        if (!pk.H_query.empty()) {
-            mix(&pk.H_query.back(), sizeof(G1<ppT>));
-        }
-        if (!pk.L_query.empty()) {
-            mix(&pk.L_query.back(), sizeof(G1<ppT>));
+        mix(&pk.delta_g2, sizeof(pk.delta_g2));
+        mix_samples(h, pk.A_query);
+        mix_samples(h, pk.B_query.indices);
+        mix_samples(h, pk.B_query.values);
+        mix_samples(h, pk.H_query);
+        mix_samples(h, pk.L_query);
+        const auto &cs = pk.constraint_system;
+        const size_t sizes[3] = {cs.num_constraints(), cs.num_variables(), cs.num_inputs()};
+        mix(sizes, sizeof(sizes));
+        const size_t nc = cs.constraints.size(), step = nc / 61 + 1;
+        for (size_t i = 0; i < nc; i += step) {
+            const linear_combination<Fr<ppT>> *lcs[3] = {&cs.constraints[i].a, &cs.constraints[i].b, &cs.constraints[i].c};
+            for (const auto *lc : lcs) {
+                for (const auto &t : lc->terms) {
+                    mix(&t.index, sizeof(t.index));
+                    mix(&t.coeff, sizeof(t.coeff));
+                }
+            }
         }
         return h;
     }
+    static void release_all()
+    {
+        state &s = st();
+        std::lock_guard<std::mutex> lock(s.m);
+        s.cache.clear();
+    }
     static std::shared_ptr<device_proving_key<ppT>> lookup(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
     {
-        static std::mutex m;
-        static std::map<const void *, entry> cache;
-        std::lock_guard<std::mutex> lock(m);
+        state &s = st();
+        std::lock_guard<std::mutex> lock(s.m);
         const uint64_t fp = fingerprint(pk);
-        auto it = cache.find(&pk);
-        if (it != cache.end() && it->second.fingerprint == fp) {
+        auto it = s.cache.find(&pk);
+        if (it != s.cache.end() && it->second.fingerprint == fp) {
+            it->second.last_use = ++s.clock;
             return it->second.key;
         }
-        entry e{fp, std::make_shared<device_proving_key<ppT>>(pk)};
-        cache[&pk] = e;
+        if (it != s.cache.end()) {
+            s.cache.erase(it); // the key at this address changed: its device copy is stale
+        }
+        while (s.cache.size() >= MAX_KEYS) {
+            auto oldest = s.cache.begin();
+            for (auto jt = s.cache.begin(); jt != s.cache.end(); ++jt) {
+                if (jt->second.last_use < oldest->second.last_use) {
+                    oldest = jt;
+                }
+            }
+            s.cache.erase(oldest);
+        }
+        entry e{fp, ++s.clock, std::make_shared<device_proving_key<ppT>>(pk)};
+        s.cache[&pk] = e;
+        if (!s.exit_hook) {
+            // registered after the first key exists, hence after the HIP runtime came up: at exit this runs before the
+            // runtime's own teardown and frees the device keys while their contexts still work
+            s.exit_hook = true;
+            std::atexit(&device_key_cache<ppT>::release_all);
+        }
         return e.key;
     }
 };
 } // namespace internal
+
+/// Drops every device key the stateless generate_proof / r1cs_gg_ppzksnark_prover keep (they are re-uploaded on the
+/// next use).  For hosts that want their HBM back, or that unload the library before exit.
+template<typename ppT> void release_device_keys() { internal::device_key_cache<ppT>::release_all(); }
 
 /// libsnark::r1cs_gg_ppzksnark_prover as Zeth calls it.  The key is uploaded on first use and stays resident for the
 /// process lifetime.  Zeth always passes force_pow_2_domain = true (groth16_snark.tcc:43-45); the device transforms
@@ -310,6 +381,12 @@ public:
     using proof = r1cs_gg_ppzksnark_proof<ppT>;
 
     static constexpr const char *name = "GROTH16";
+
+    /// generate_proof(pk, pb) (groth16_snark.hpp:32-35, .tcc:27-34): the protoboard's own split of its assignment
+    static proof generate_proof(const proving_key &proving_key, const protoboard<Fr<ppT>> &pb)
+    {
+        return generate_proof(proving_key, pb.primary_input(), pb.auxiliary_input());
+    }
 
     static proof generate_proof(
         const proving_key &proving_key, const r1cs_primary_input<Fr<ppT>> &primary_input, const r1cs_auxiliary_input<Fr<ppT>> auxiliary_input)
@@ -379,7 +456,8 @@ public:
 template<typename ppT, typename GroupT> class resident_bases
 {
 public:
-    explicit resident_bases(const std::vector<GroupT> &gs, int device = 0) : dc_(device_context::get(device)), handle_(nullptr), size_(gs.size())
+    explicit resident_bases(const std::vector<GroupT> &gs, int device = 0)
+        : dcp_(device_context::get_shared(device)), dc_(*dcp_), handle_(nullptr), size_(gs.size())
     {
         std::lock_guard<std::mutex> lock(dc_.mutex());
         check(zg_bases_create(dc_.ctx(), ppT::curve_id, GroupT::group_id, gs.data(), gs.size(), ZG_FORM_PLAIN, ZG_MEM_HOST, &handle_));
@@ -412,6 +490,7 @@ public:
     GroupT multi_exp(const Fr_vector<ppT> &fs) const { return multi_exp(fs.data(), fs.size(), 0); }
 
 private:
+    std::shared_ptr<device_context> dcp_;
     device_context &dc_;
     zg_bases *handle_;
     size_t size_;

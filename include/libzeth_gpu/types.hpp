@@ -178,6 +178,28 @@ template<typename FieldT> using r1cs_primary_input = std::vector<FieldT>;
 template<typename FieldT> using r1cs_auxiliary_input = std::vector<FieldT>;
 template<typename FieldT> using r1cs_variable_assignment = std::vector<FieldT>;
 
+/// The part of libsnark::protoboard<FieldT> the proving entry point reads (circuit_wrapper.tcc:150-170 fills it, then
+/// groth16_snark::generate_proof(pk, pb) takes pb.primary_input() / pb.auxiliary_input(), groth16_snark.tcc:27-34):
+/// the full assignment without the constant ONE, primary inputs first.
+template<typename FieldT> struct protoboard {
+    r1cs_variable_assignment<FieldT> values;
+    size_t num_inputs_ = 0;
+    void set_input_sizes(size_t primary_input_size)
+    {
+        if (primary_input_size > values.size()) {
+            throw std::invalid_argument("protoboard: more inputs than variables");
+        }
+        num_inputs_ = primary_input_size;
+    }
+    size_t num_inputs() const { return num_inputs_; }
+    size_t num_variables() const { return values.size(); }
+    /// variable `index` (1-based, as in libsnark; 0 is the constant ONE)
+    FieldT &val(var_index_t index) { return values.at(index - 1); }
+    const r1cs_variable_assignment<FieldT> &full_variable_assignment() const { return values; }
+    r1cs_primary_input<FieldT> primary_input() const { return r1cs_primary_input<FieldT>(values.begin(), values.begin() + num_inputs_); }
+    r1cs_auxiliary_input<FieldT> auxiliary_input() const { return r1cs_auxiliary_input<FieldT>(values.begin() + num_inputs_, values.end()); }
+};
+
 template<typename T> struct sparse_vector {
     std::vector<size_t> indices;
     std::vector<T> values;

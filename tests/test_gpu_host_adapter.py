@@ -90,6 +90,25 @@ def test_adapter_generate_proof(curve, tmp_path):
     assert M.verify(C, vk, primary, M.proof_from_bytes(C, p1)) and M.verify(C, vk, primary, M.proof_from_bytes(C, p2))
 
 
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_adapter_generate_proof_from_protoboard_as_first_call(curve, tmp_path):
+    """groth16_snark<ppT>::generate_proof(pk, pb) (groth16_snark.hpp:32-35, .tcc:27-34; what circuit_wrapper::prove
+    calls, circuit_wrapper.tcc:169-170) as the FIRST call into the library; the same host key object then changed in
+    place (the device copy kept by the stateless entry point must be rebuilt); device keys released and proved again;
+    clean exit (no use of a destroyed context in static destructors)."""
+    C = CURVES[curve]
+    cs, pk, vk, primary, aux = simple_instance(C, [3, 5])
+    pk2, vk2 = M.generator_from_secrets(C, cs, 0x7654321, 0x2345678, 0x3456789, 0x456789A)
+    (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
+    (tmp_path / "pk2").write_bytes(M.proving_key_to_bytes(C, pk2))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    run(DRIVER, "prove_pb", curve, tmp_path / "pk", tmp_path / "asg", 1, tmp_path / "pk2", tmp_path / "p1", tmp_path / "p2", tmp_path / "p3")
+    p1, p2, p3 = ((tmp_path / n).read_bytes() for n in ("p1", "p2", "p3"))
+    assert M.verify(C, vk, primary, M.proof_from_bytes(C, p1))
+    assert M.verify(C, vk2, primary, M.proof_from_bytes(C, p2)) and not M.verify(C, vk, primary, M.proof_from_bytes(C, p2))
+    assert M.verify(C, vk2, primary, M.proof_from_bytes(C, p3))
+
+
 @pytest.mark.parametrize("curve,group", [("alt-bn128", "g1"), ("alt-bn128", "g2"), ("bls12-377", "g1"), ("bls12-377", "g2")])
 def test_adapter_multi_exp(curve, group, tmp_path):
     """libzeth::multi_exp<ppT, GroupT>(gs, fs) (multi_exp.tcc:25-35): more bases than scalars is allowed and uses the

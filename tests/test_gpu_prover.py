@@ -197,3 +197,26 @@ def generator_from_secrets_fast(C, cs, rng):
     pk.H_query = walk(G1, m - 1)
     pk.L_query = walk(G1, nv - ni)
     return pk, None
+
+
+def test_failed_prove_is_followed_by_a_correct_proof(ctx, monkeypatch):
+    """An error after the lanes were queued (forced through the library's test hook) drains every stream before it is
+    returned: the next zg_prove on the same key gives the oracle's proof."""
+    import zeth_amd
+
+    C = BN254
+    rng = random.Random(99)
+    cs, primary, aux = random_r1cs(C, rng, 2, 900, 1500)
+    pk, _ = generator_from_secrets_fast(C, cs, rng)
+    dpk = zeth_amd.ProvingKey.from_model(ctx, 0, pk, C.r)
+    snark = zeth_amd.Groth16Snark(ctx, 0)
+    want = cpu_oracle.prove(0, C, pk, primary, aux, 5, 7, chunks=2)
+    assert snark.generate_proof(dpk, primary, aux, 5, 7) == want
+    for lane in ("0", "2", "4"):
+        monkeypatch.setenv("ZG_TEST_FAIL_LANE", lane)
+        with pytest.raises(zeth_amd.ZethGpuError) as e:
+            snark.generate_proof(dpk, primary, aux, 5, 7)
+        assert e.value.status == -4
+        monkeypatch.delenv("ZG_TEST_FAIL_LANE")
+        assert snark.generate_proof(dpk, primary, aux, 5, 7) == want
+    dpk.free()

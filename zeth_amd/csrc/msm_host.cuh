@@ -33,14 +33,20 @@ __global__ void __launch_bounds__(256) k_to_mont(B* __restrict__ elems, size_t c
 
 static constexpr uint32_t GEN_CHUNK = 64;
 
-// Measurement knob (wrong results by design): ZG_DEBUG_BASE_MASK=0xffff makes every gather of the accumulation
-// kernel hit the first 2^16 bases, which separates its arithmetic time from its memory time.
+// Measurement knob, compiled in only with -DZG_DEBUG_KNOBS (tools/ builds): ZG_DEBUG_BASE_MASK=0xffff makes every gather
+// of the accumulation kernel hit the first 2^16 bases -- wrong results by design -- which separates the kernel's
+// arithmetic time from its memory time.  The shipped library ignores the variable.
 inline uint32_t zg_debug_base_mask() {
+#ifdef ZG_DEBUG_KNOBS
   static const uint32_t mask = [] {
     const char* e = getenv("ZG_DEBUG_BASE_MASK");
+    if (e) fprintf(stderr, "zeth_gpu: ZG_DEBUG_BASE_MASK is set: every MSM result of this process is WRONG by design\n");
     return e ? (uint32_t)strtoul(e, nullptr, 0) & 0x7FFFFFFFu : 0x7FFFFFFFu;
   }();
   return mask;
+#else
+  return 0x7FFFFFFFu;
+#endif
 }
 
 // lane j: points [j*64, j*64+64): start (t0 + j*64*d) * G by double-and-add, then repeated + D

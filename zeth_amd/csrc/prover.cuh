@@ -348,8 +348,9 @@ struct ProvingKeyDev : PkBase {
     // Witness scalars are mostly 0/1: the windows of these four evaluations are sized by the number
     // of other ("dense") scalars the same evaluation saw in the previous proof with this key -- the role libff's
     // 0/1 filter plays in multi_exp_with_mixed_addition.  Any width gives the same group element.
-    // the longest dependent chain (constraint evaluation, seven transforms, H evaluation) goes first, on the
-    // high-priority main stream; the side lanes have the lowest stream priority
+    // the longest dependent chain (constraint evaluation, seven transforms, H evaluation) is queued by this thread on
+    // the main stream; the side lanes run at the SAME stream priority (with the lowest priority they starved behind
+    // the main stream's kernels: a proof did not finish in 100 s)
     static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
     static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
     auto width = [](uint32_t dense) { return lane_c ? lane_c : dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
@@ -388,6 +389,24 @@ struct ProvingKeyDev : PkBase {
         workers[i].join();
       else
         queue_lane(i);
+    }
+    // From here on kernels of this proof are queued on five streams; they read w, bsc and tmp and write the lanes' pinned
+    // buffers.  Whatever fails below, every stream is drained before the error is returned, so that the next proof on
+    // this key starts on idle lanes.
+    struct Drain {
+      ProvingKeyDev* pk;
+      bool armed = true;
+      ~Drain() {
+        if (!armed) return;
+        hipStreamSynchronize(pk->ctx->stream);
+        for (auto* l : pk->lane)
+          if (l) hipStreamSynchronize(l->stream);
+      }
+    } drain{this};
+    if (const char* inj = getenv("ZG_TEST_FAIL_LANE")) {  // test hook: pretend that lane's queueing failed
+      const int which = atoi(inj);
+      if (which >= 0 && which < 4) lane_status[which] = ZG_ERR_HIP;
+      if (which == 4) h_status = ZG_ERR_HIP;
     }
     ZG_TRY(h_status);
     for (int i = 0; i < 4; i++) ZG_TRY(lane_status[i]);
@@ -449,6 +468,7 @@ struct ProvingKeyDev : PkBase {
     }
     memcpy(proof_out, &proof, sizeof(proof));
     stamp("proof normalised");
+    drain.armed = false;  // every msm_finish above has synchronised its stream
     return ZG_OK;
   }
 

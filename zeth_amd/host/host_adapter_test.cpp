@@ -8,6 +8,10 @@
 //   domain CURVE fft|ifft|cosetfft|icosetfft scalars_in scalars_out
 //   lagrange CURVE g1|g2 powers out_points      evaluator_from_lagrange for every single-index factor map (evaluator_from_lagrange_test.cpp:44-65)
 //   prove CURVE pk assignment primary_inputs r_hex s_hex proof_fixed proof_random_1 proof_random_2
+//   prove_pb CURVE pk assignment primary_inputs pk2 proof_1 proof_2 proof_3
+//          the FIRST library call is generate_proof(pk, pb) (groth16_snark.hpp:32-35); then the host key is overwritten in
+//          place with pk2 (same address, same sizes) and proved again: the stale device copy must not be used; then the
+//          device keys are released and the key proved once more; the process must exit cleanly
 #include <iostream>
 
 #include "../../include/libzeth_gpu/gpu_groth16_snark.hpp"
@@ -222,6 +226,49 @@ template<typename ppT> int cmd_prove(char **argv)
     return 0;
 }
 
+template<typename ppT> int cmd_prove_pb(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    typename snarkT::proving_key pk;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        snarkT::proving_key_read_bytes(pk, in_s);
+    }
+    protoboard<Fr<ppT>> pb;
+    {
+        r1cs_primary_input<Fr<ppT>> primary;
+        r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+        std::ifstream in_s = open_binary_input_file(argv[4]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[5]), in_s);
+        pb.values = primary;
+        pb.values.insert(pb.values.end(), auxiliary.begin(), auxiliary.end());
+        pb.set_input_sizes(primary.size());
+    }
+    auto write = [](const typename snarkT::proof &proof, const char *path) {
+        std::ofstream out_s = open_binary_output_file(path);
+        snarkT::proof_write_bytes(proof, out_s);
+    };
+    write(snarkT::generate_proof(pk, pb), argv[7]); // nothing of the library has run before this call
+    {
+        typename snarkT::proving_key pk2;
+        std::ifstream in_s = open_binary_input_file(argv[6]);
+        snarkT::proving_key_read_bytes(pk2, in_s);
+        pk.alpha_g1 = pk2.alpha_g1; // in place: the address the cache knows now holds another key
+        pk.beta_g1 = pk2.beta_g1;
+        pk.beta_g2 = pk2.beta_g2;
+        pk.delta_g1 = pk2.delta_g1;
+        pk.delta_g2 = pk2.delta_g2;
+        std::copy(pk2.A_query.begin(), pk2.A_query.end(), pk.A_query.begin());
+        std::copy(pk2.B_query.values.begin(), pk2.B_query.values.end(), pk.B_query.values.begin());
+        std::copy(pk2.H_query.begin(), pk2.H_query.end(), pk.H_query.begin());
+        std::copy(pk2.L_query.begin(), pk2.L_query.end(), pk.L_query.begin());
+    }
+    write(snarkT::generate_proof(pk, pb), argv[8]);
+    release_device_keys<ppT>();
+    write(snarkT::generate_proof(pk, pb), argv[9]);
+    return 0; // the remaining device key is released by the exit hook
+}
+
 // groth16_snark_test.cpp:39-171 (generate_test_data): the hand-made constraint system, proving key and assignment
 template<typename ppT> int cmd_testdata(char **argv)
 {
@@ -330,6 +377,9 @@ template<typename ppT> int run(int argc, char **argv)
     }
     if (cmd == "prove" && argc >= 11) {
         return cmd_prove<ppT>(argv);
+    }
+    if (cmd == "prove_pb" && argc >= 10) {
+        return cmd_prove_pb<ppT>(argv);
     }
     std::cerr << "usage: see the head of host_adapter_test.cpp\n";
     return 2;
