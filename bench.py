@@ -399,6 +399,7 @@ def main():
             },
             "phases_ms": {k2: v / args.steps for k2, v in phase_ms.items()},
         }
+        out["hip_runtime"] = zeth_amd.runtime_info()  # which libamdhip64 / libhsa-runtime64 served this run
         if windowed is not None:
             out["windowed"] = windowed
             out["windowed_ms_per_step"] = windowed["ms_per_step"]

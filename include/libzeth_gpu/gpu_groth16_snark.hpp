@@ -13,6 +13,7 @@
 #ifndef LIBZETH_GPU_GROTH16_SNARK_HPP
 #define LIBZETH_GPU_GROTH16_SNARK_HPP
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -193,6 +194,44 @@ template<typename ppT> Fr<ppT> random_field_element()
         }
     }
 }
+
+/// One resident copy of the proving key per device, provers handed out round-robin: prover_server's handlers
+/// (prover_server/prover_server.cpp:192-201) call prove() concurrently and every call runs on the next device's key.
+/// Independent proofs are replicas -- no exchange between devices.  One process, N devices.
+template<typename ppT> class device_proving_key_pool
+{
+public:
+    device_proving_key_pool(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, const std::vector<int> &devices) : next_(0)
+    {
+        if (devices.empty()) {
+            throw std::invalid_argument("device_proving_key_pool: no devices");
+        }
+        for (int d : devices) {
+            keys_.emplace_back(new device_proving_key<ppT>(pk, d));
+        }
+    }
+    size_t size() const { return keys_.size(); }
+    r1cs_gg_ppzksnark_proof<ppT> prove(
+        const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary, const Fr<ppT> &r, const Fr<ppT> &s)
+    {
+        size_t k;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            k = next_;
+            next_ = (next_ + 1) % keys_.size();
+        }
+        return keys_[k]->prove(primary, auxiliary, r, s); // serialised per device by the device context's mutex
+    }
+    r1cs_gg_ppzksnark_proof<ppT> prove(const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary)
+    {
+        return prove(primary, auxiliary, random_field_element<ppT>(), random_field_element<ppT>());
+    }
+
+private:
+    std::vector<std::unique_ptr<device_proving_key<ppT>>> keys_;
+    std::mutex m_;
+    size_t next_;
+};
 
 namespace internal
 {
@@ -494,6 +533,73 @@ private:
     device_context &dc_;
     zg_bases *handle_;
     size_t size_;
+};
+
+/// libzeth::multi_exp over several devices: the bases cut into one contiguous range per device and kept resident
+/// there (zg_msm_sharded); multi_exp(fs) cuts the scalars the same way.  The "sum over chunks" of libff::multi_exp with
+/// one chunk per GPU.
+template<typename ppT, typename GroupT> class sharded_bases
+{
+public:
+    sharded_bases(const std::vector<GroupT> &gs, const std::vector<int> &devices) : size_(gs.size())
+    {
+        if (devices.empty()) {
+            throw std::invalid_argument("sharded_bases: no devices");
+        }
+        const size_t n = gs.size(), k = devices.size();
+        for (size_t i = 0; i < k; i++) {
+            const size_t lo = n * i / k, hi = n * (i + 1) / k;
+            zg_ctx *c = nullptr;
+            check(zg_ctx_create(devices[i], &c)); // a context of its own per shard: shards run concurrently
+            ctxs_.push_back(c);
+            zg_bases *b = nullptr;
+            check(zg_bases_create(c, ppT::curve_id, GroupT::group_id, gs.data() + lo, hi - lo, ZG_FORM_PLAIN, ZG_MEM_HOST, &b));
+            shards_.push_back(b);
+            first_.push_back(lo);
+        }
+        first_.push_back(n);
+    }
+    ~sharded_bases()
+    {
+        for (zg_bases *b : shards_) {
+            zg_bases_free(b);
+        }
+        for (zg_ctx *c : ctxs_) {
+            zg_ctx_destroy(c);
+        }
+    }
+    sharded_bases(const sharded_bases &) = delete;
+    sharded_bases &operator=(const sharded_bases &) = delete;
+    void precompute(int window_bits = 0)
+    {
+        for (zg_bases *b : shards_) {
+            check(zg_bases_precompute(b, window_bits));
+        }
+    }
+    GroupT multi_exp(const Fr_vector<ppT> &fs)
+    {
+        if (fs.size() > size_) {
+            throw std::invalid_argument("multi_exp: fewer bases than scalars"); // multi_exp.tcc:28-29
+        }
+        std::vector<const void *> ptrs;
+        std::vector<size_t> counts;
+        for (size_t i = 0; i < shards_.size(); i++) {
+            const size_t lo = std::min(first_[i], fs.size()), hi = std::min(first_[i + 1], fs.size());
+            ptrs.push_back(fs.data() + lo);
+            counts.push_back(hi - lo);
+        }
+        GroupT out;
+        std::lock_guard<std::mutex> lock(m_);
+        check(zg_msm_sharded(shards_.data(), shards_.size(), ptrs.data(), counts.data(), ZG_FORM_PLAIN, ZG_MEM_HOST, ZG_FORM_PLAIN, &out));
+        return out;
+    }
+
+private:
+    std::vector<zg_ctx *> ctxs_;
+    std::vector<zg_bases *> shards_;
+    std::vector<size_t> first_;
+    size_t size_;
+    std::mutex m_;
 };
 
 template<typename ppT, typename GroupT>

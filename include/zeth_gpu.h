@@ -110,6 +110,21 @@ int zg_msm(zg_bases* bases, size_t first, const void* scalars, size_t n, int sca
 int zg_msm_ex(zg_bases* bases, size_t first, const void* scalars, size_t n, int scalar_form, int scalars_mem,
               int out_form, void* out_affine, int window_bits);
 
+/* One multi-exponentiation sharded by point range over several devices (what libff::multi_exp does with its
+ * OpenMP chunks, here one chunk per GPU): shard i is a set of resident bases created on its own context (normally one
+ * context per HIP device; two contexts on one device also work), scalars[i] are its counts[i] Fr scalars (host memory, or
+ * memory of shard i's device, per scalars_mem) for its bases [0, counts[i]).  Every shard is driven by a host thread of
+ * its own; the n_shards partial points are added on the host.  One process, N devices, no collective library needed.
+ * The shards must share curve and group and sit on distinct contexts -> else ZG_ERR_INVALID_ARGUMENT. */
+int zg_msm_sharded(zg_bases* const* shards, size_t n_shards, const void* const* scalars, const size_t* counts,
+                   int scalar_form, int scalars_mem, int out_form, void* out_affine);
+
+/* Which ROCm runtime serves this process, as a JSON object in buf: the libamdhip64 this library is bound to, its version,
+ * and every libamdhip64 / libhsa-runtime64 image mapped into the process.  *mixed = 1 when more than one copy of either
+ * is loaded or HIP and HSA come from different installations (a host that imports another ROCm copy, e.g. a Python
+ * wheel's, next to the system one): results are then only as good as that mixture -- see DESIGN.md section 7. */
+int zg_runtime_info(char* buf, size_t cap, int* mixed);
+
 /* In-place radix-2 evaluation-domain transform of 2^log_n Fr elements (natural order in and out):
  *   inverse = 0, coset = 0   domain.FFT(a)           inverse = 1, coset = 0   domain.iFFT(a)
  *   inverse = 0, coset = 1   domain.cosetFFT(a, g)    inverse = 1, coset = 1   domain.icosetFFT(a, g)

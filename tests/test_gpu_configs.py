@@ -171,3 +171,38 @@ def test_g2_msm_2p18_closed_form(ctx, curve):
     part.free()
     sc.free()
     bases.free()
+
+
+@pytest.mark.parametrize("curve,group", [("alt-bn128", 1), ("alt-bn128", 2), ("bls12-377", 1)])
+def test_msm_sharded_two_contexts_on_one_device(curve, group):
+    """configs[2] behind the C ABI: zg_msm_sharded over two contexts (on a node: two devices), each with its point range
+    and its scalar slice resident, with and without the fixed-base table; closed form and the CPU oracle on a prefix."""
+    import zeth_amd
+    from zeth_amd.synth import closed_form_scalar, random_scalars_host
+
+    cid, C = CURVES[curve]
+    G = C.G1 if group == 1 else C.G2
+    n = 1 << 16
+    t0, d = 0x5A45 + cid, 0x77777
+    ctxs = [zeth_amd.Context(0), zeth_amd.Context(0)]
+    cuts = [0, n // 3, n]  # unequal ranges
+    words = random_scalars_host(n, C.r, 4242 + group)
+    shards, scal, counts = [], [], []
+    for i, c in enumerate(ctxs):
+        lo, hi = cuts[i], cuts[i + 1]
+        shards.append(zeth_amd.Bases.generate(c, cid, group, hi - lo, (t0 + lo * d) % C.r, d))
+        scal.append(zeth_amd.DeviceBuffer.from_bytes(c, words[lo:hi].tobytes()))
+        counts.append(hi - lo)
+    want = G.mul(closed_form_scalar(words, t0, d, C.r), G.gen)
+    assert zeth_amd.msm_sharded(shards, scal, counts) == want
+    for b in shards:
+        b.precompute()
+    assert zeth_amd.msm_sharded(shards, scal, counts) == want
+    # fewer scalars than bases in the last shard, an empty shard
+    assert zeth_amd.msm_sharded(shards, scal, [counts[0], 0]) == G.mul(closed_form_scalar(words[: counts[0]], t0, d, C.r), G.gen)
+    info = zeth_amd.runtime_info()
+    assert info["hip_bound"] and info["hip_runtime_version"] > 0
+    for x in scal + shards:
+        x.free()
+    for c in ctxs:
+        c.close()

@@ -130,6 +130,38 @@ def test_adapter_multi_exp(curve, group, tmp_path):
     run(DRIVER, "multi_exp", curve, group, tmp_path / "few", tmp_path / "fs", tmp_path / "out2", expect=10)
 
 
+@pytest.mark.parametrize("curve,group,shards", [("alt-bn128", "g1", 3), ("alt-bn128", "g2", 2), ("bls12-377", "g1", 2), ("bls12-377", "g2", 4)])
+def test_adapter_multi_exp_sharded(curve, group, shards, tmp_path):
+    """sharded_bases<ppT, GroupT>::multi_exp over zg_msm_sharded: the bases cut into point ranges, one context (here all on
+    device 0; on a node one per device) and one host thread per range, partial points added on the host -- against the
+    oracle's multi_exp (libzeth::multi_exp, multi_exp.tcc:25-35), also with fewer scalars than bases."""
+    C = CURVES[curve]
+    G = C.G1 if group == "g1" else C.G2
+    to_bytes = M.g1_vector_to_bytes if group == "g1" else M.g2_vector_to_bytes
+    one_to_bytes = M.g1_to_bytes if group == "g1" else M.g2_to_bytes
+    rng = random.Random(13 + shards)
+    n = 1500
+    pts = [G.mul(rng.randrange(1, C.r), G.gen) for _ in range(8)]
+    gs = [pts[i % 8] if i % 19 else None for i in range(n + 40)]
+    fs = [rng.choice([0, 1, C.r - 1, rng.randrange(C.r)]) for _ in range(n)]
+    (tmp_path / "gs").write_bytes(to_bytes(C, gs))
+    (tmp_path / "fs").write_bytes(M.assignment_to_bytes(C, fs))
+    run(DRIVER, "multi_exp_sharded", curve, group, tmp_path / "gs", tmp_path / "fs", tmp_path / "out", shards)
+    assert (tmp_path / "out").read_bytes() == one_to_bytes(C, G.multi_exp(gs[:n], fs))
+
+
+def test_adapter_proving_key_pool(tmp_path):
+    """device_proving_key_pool: one resident key per device, provers handed out round-robin (here two copies on device 0)."""
+    C = CURVES["alt-bn128"]
+    cs, pk, vk, primary, aux = simple_instance(C, [7, 9])
+    (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    r, s = 0xABCDEF % C.r, 0x123456789 % C.r
+    run(DRIVER, "prove_pool", "alt-bn128", tmp_path / "pk", tmp_path / "asg", 1, "%x" % r, "%x" % s, tmp_path / "a", tmp_path / "b")
+    want = M.proof_to_bytes(C, M.prove(C, pk, primary, aux, r, s))
+    assert (tmp_path / "a").read_bytes() == want and (tmp_path / "b").read_bytes() == want
+
+
 @pytest.mark.parametrize("curve", sorted(CURVES))
 def test_adapter_domain(curve, tmp_path):
     C = CURVES[curve]

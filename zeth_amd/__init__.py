@@ -20,4 +20,6 @@ from .lib import (  # noqa: F401
     group_sparse_combine,
     host_group_op,
     load_library,
+    msm_sharded,
+    runtime_info,
 )

@@ -1,8 +1,13 @@
 // C ABI (include/zeth_gpu.h): argument checking, contexts, resident bases, MSM entry points.
+#include <dlfcn.h>
+#include <link.h>
 #include <string.h>
 
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "common.cuh"
 
@@ -554,3 +559,81 @@ int zg_host_points_check(int curve, int group, const void* points, size_t n, int
 }
 
 }  // extern "C"
+
+// ---- which ROCm runtime serves this process --------------------------------------------------------------------
+namespace {
+struct RtScan {
+  std::vector<std::string> hip, hsa;
+};
+int rt_scan_cb(struct dl_phdr_info* info, size_t, void* data) {
+  RtScan* r = static_cast<RtScan*>(data);
+  const char* n = info->dlpi_name;
+  if (!n || !*n) return 0;
+  if (strstr(n, "libamdhip64")) r->hip.push_back(n);
+  if (strstr(n, "libhsa-runtime64")) r->hsa.push_back(n);
+  return 0;
+}
+std::string dir_of(const std::string& path) {
+  const size_t k = path.rfind('/');
+  return k == std::string::npos ? std::string() : path.substr(0, k);
+}
+}  // namespace
+
+extern "C" int zg_runtime_info(char* buf, size_t cap, int* mixed) {
+  if (!buf || cap == 0) return ZG_ERR_INVALID_ARGUMENT;
+  RtScan r;
+  dl_iterate_phdr(rt_scan_cb, &r);
+  Dl_info bound;
+  std::string mine;
+  if (dladdr((void*)&hipGetDeviceCount, &bound) && bound.dli_fname) mine = bound.dli_fname;
+  int ver = 0;
+  (void)hipRuntimeGetVersion(&ver);
+  bool mix = r.hip.size() > 1 || r.hsa.size() > 1;
+  if (!mine.empty() && !r.hsa.empty() && dir_of(mine) != dir_of(r.hsa[0])) mix = true;  // HIP of one installation over HSA of another
+  std::string out = "{\"hip_bound\": \"" + mine + "\", \"hip_runtime_version\": " + std::to_string(ver) + ", \"hip_loaded\": [";
+  for (size_t i = 0; i < r.hip.size(); i++) out += std::string(i ? ", " : "") + "\"" + r.hip[i] + "\"";
+  out += "], \"hsa_loaded\": [";
+  for (size_t i = 0; i < r.hsa.size(); i++) out += std::string(i ? ", " : "") + "\"" + r.hsa[i] + "\"";
+  out += std::string("], \"mixed_installations\": ") + (mix ? "true" : "false") + "}";
+  if (mixed) *mixed = mix ? 1 : 0;
+  if (out.size() + 1 > cap) return ZG_ERR_LENGTH;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return ZG_OK;
+}
+
+// ---- one multi-exponentiation over several devices -----------------------------------------------------------------
+extern "C" int zg_msm_sharded(zg_bases* const* shards, size_t n_shards, const void* const* scalars, const size_t* counts,
+                              int scalar_form, int scalars_mem, int out_form, void* out_affine) {
+  if (!shards || !n_shards || !scalars || !counts || !out_affine) return ZG_ERR_INVALID_ARGUMENT;
+  if (out_form != ZG_FORM_PLAIN && out_form != ZG_FORM_MONT) return ZG_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < n_shards; i++) {
+    if (!shards[i] || (counts[i] && !scalars[i])) return ZG_ERR_INVALID_ARGUMENT;
+    if (shards[i]->curve != shards[0]->curve || shards[i]->group != shards[0]->group) return ZG_ERR_INVALID_ARGUMENT;
+    for (size_t j = 0; j < i; j++)
+      if (shards[j]->ctx == shards[i]->ctx) return ZG_ERR_INVALID_ARGUMENT;  // calls on one context must not overlap
+  }
+  const size_t ab = shards[0]->ops->affine_bytes;
+  std::vector<unsigned char> partial(n_shards * ab);
+  std::vector<int> status(n_shards, ZG_OK);
+  auto run = [&](size_t i) {
+    // each shard: its own device, context and stream; partial result = one affine point (Montgomery)
+    status[i] = zg_msm(shards[i], 0, scalars[i], counts[i], scalar_form, scalars_mem, ZG_FORM_MONT, partial.data() + i * ab);
+  };
+  std::vector<std::thread> workers;
+  for (size_t i = 1; i < n_shards; i++) {
+    try {
+      workers.emplace_back(run, i);
+    } catch (const std::system_error&) {
+      run(i);  // no thread to be had: this shard runs on the calling thread
+    }
+  }
+  run(0);
+  for (auto& w : workers) w.join();
+  for (size_t i = 0; i < n_shards; i++) ZG_TRY(status[i]);
+  // the "sum over chunks" of libff::multi_exp: n_shards points, on the host
+  unsigned char sum[4 * 48 * 2];
+  ZG_TRY(shards[0]->ops->host_sum(partial.data(), n_shards, ZG_FORM_MONT, sum));
+  if (out_form == ZG_FORM_PLAIN) shards[0]->ops->host_convert(sum, 1, 0);
+  memcpy(out_affine, sum, ab);
+  return ZG_OK;
+}

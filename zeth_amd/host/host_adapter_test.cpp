@@ -8,6 +8,8 @@
 //   domain CURVE fft|ifft|cosetfft|icosetfft scalars_in scalars_out
 //   lagrange CURVE g1|g2 powers out_points      evaluator_from_lagrange for every single-index factor map (evaluator_from_lagrange_test.cpp:44-65)
 //   prove CURVE pk assignment primary_inputs r_hex s_hex proof_fixed proof_random_1 proof_random_2
+//   multi_exp_sharded CURVE g1|g2 points scalars out_point n_shards     sharded_bases over n_shards contexts on device 0
+//   prove_pool CURVE pk assignment primary_inputs r_hex s_hex proof_a proof_b     device_proving_key_pool over {0, 0}
 //   prove_pb CURVE pk assignment primary_inputs pk2 proof_1 proof_2 proof_3
 //          the FIRST library call is generate_proof(pk, pb) (groth16_snark.hpp:32-35); then the host key is overwritten in
 //          place with pk2 (same address, same sizes) and proved again: the stale device copy must not be used; then the
@@ -125,6 +127,23 @@ template<typename ppT, typename GroupT> int cmd_multi_exp(char **argv)
     return 0;
 }
 
+template<typename ppT, typename GroupT> int cmd_multi_exp_sharded(char **argv)
+{
+    const std::vector<GroupT> gs = read_points<ppT, GroupT>(argv[4]);
+    const std::vector<Fr<ppT>> fs = read_scalars<ppT>(argv[5]);
+    const std::vector<int> devices(std::stoul(argv[7]), 0); // every shard on device 0, each with a context of its own
+    sharded_bases<ppT, GroupT> sb(gs, devices);
+    const GroupT sum = sb.multi_exp(fs);
+    sb.precompute(12);
+    if (sb.multi_exp(fs) != sum) {
+        std::cerr << "sharded_bases::multi_exp with tables disagrees with the plain form\n";
+        return 1;
+    }
+    std::ofstream out_s = open_binary_output_file(argv[6]);
+    group_element_write_bytes(sum, out_s);
+    return 0;
+}
+
 template<typename ppT> int cmd_domain(char **argv)
 {
     std::vector<Fr<ppT>> a = read_scalars<ppT>(argv[4]);
@@ -222,6 +241,29 @@ template<typename ppT> int cmd_prove(char **argv)
     if (!threw) {
         std::cerr << "a short assignment did not raise invalid_argument\n";
         return 1;
+    }
+    return 0;
+}
+
+template<typename ppT> int cmd_prove_pool(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    typename snarkT::proving_key pk;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        snarkT::proving_key_read_bytes(pk, in_s);
+    }
+    r1cs_primary_input<Fr<ppT>> primary;
+    r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[4]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[5]), in_s);
+    }
+    device_proving_key_pool<ppT> pool(pk, {0, 0}); // two resident copies; on a node: one per device
+    for (int k = 0; k < 2; k++) {
+        const typename snarkT::proof proof = pool.prove(primary, auxiliary, from_hex<4>(argv[6]), from_hex<4>(argv[7]));
+        std::ofstream out_s = open_binary_output_file(argv[8 + k]);
+        snarkT::proof_write_bytes(proof, out_s);
     }
     return 0;
 }
@@ -368,6 +410,12 @@ template<typename ppT> int run(int argc, char **argv)
     }
     if (cmd == "multi_exp" && argc >= 7) {
         return std::string(argv[3]) == "g1" ? cmd_multi_exp<ppT, G1<ppT>>(argv) : cmd_multi_exp<ppT, G2<ppT>>(argv);
+    }
+    if (cmd == "multi_exp_sharded" && argc >= 8) {
+        return std::string(argv[3]) == "g1" ? cmd_multi_exp_sharded<ppT, G1<ppT>>(argv) : cmd_multi_exp_sharded<ppT, G2<ppT>>(argv);
+    }
+    if (cmd == "prove_pool" && argc >= 10) {
+        return cmd_prove_pool<ppT>(argv);
     }
     if (cmd == "domain" && argc >= 6) {
         return cmd_domain<ppT>(argv);

@@ -81,6 +81,8 @@ def load_library():
     L.zg_msm.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp]
     L.zg_msm_ex.argtypes = [vp, sz, vp, sz, ci, ci, ci, vp, ci]
     L.zg_ntt.argtypes = [vp, ci, vp, ctypes.c_uint, ci, ci, ci, ci]
+    L.zg_msm_sharded.argtypes = [ctypes.POINTER(vp), sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ci, ci, ci, vp]
+    L.zg_runtime_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ci)]
     L.zg_ntt_noalloc.argtypes = [vp, ci, vp, ctypes.c_uint, ci, ci, ci]
     L.zg_pk_create.argtypes = [vp, ci, ctypes.POINTER(PkView), ctypes.POINTER(vp)]
     L.zg_pk_free.argtypes = [vp]
@@ -320,6 +322,28 @@ class Bases:
             self.free()
         except Exception:
             pass
+
+
+def runtime_info() -> dict:
+    """zg_runtime_info: which libamdhip64 / libhsa-runtime64 images serve this process."""
+    import json
+
+    buf = ctypes.create_string_buffer(8192)
+    mixed = ctypes.c_int(0)
+    _check(load_library().zg_runtime_info(buf, len(buf), ctypes.byref(mixed)))
+    return json.loads(buf.value.decode())
+
+
+def msm_sharded(shards: Sequence["Bases"], scalars: Sequence["DeviceBuffer"], counts: Sequence[int]):
+    """zg_msm_sharded over resident-base shards (one context each) with device-resident scalar slices -> affine point."""
+    n = len(shards)
+    L = shards[0]._L
+    hs = (ctypes.c_void_p * n)(*[b._h for b in shards])
+    ps = (ctypes.c_void_p * n)(*[ctypes.c_void_p(s.ptr) for s in scalars])
+    cs = (ctypes.c_size_t * n)(*counts)
+    out = ctypes.create_string_buffer(affine_bytes(shards[0].curve, shards[0].group))
+    _check(L.zg_msm_sharded(hs, n, ps, cs, FORM_PLAIN, MEM_DEVICE, FORM_PLAIN, out))
+    return decode_point(shards[0].curve, shards[0].group, out.raw)
 
 
 class EvaluationDomain:
