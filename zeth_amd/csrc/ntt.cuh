@@ -23,6 +23,9 @@ namespace zg {
 
 static constexpr int NTT_LDS_ELEMS = 4096;  // 128 KB of 32-byte elements
 static constexpr int NTT_THREADS = 1024;
+// most threads of a workgroup whose rounds take RMAX stages: a work item of 2^RMAX elements per thread, and registers
+// for them (radix 8: ~150 VGPRs, so at most 512 threads)
+constexpr int ntt_max_threads(int rmax) { return rmax >= 3 ? 512 : 1024; }
 
 template <class Fr>
 struct NttTables {
@@ -88,54 +91,117 @@ ZG_HD Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t half_m) {
   return (e & half_m) ? Fr::neg(w) : w;
 }
 
-// `cols` interleaved transforms of size 2^logS held in LDS as lds[pos * cols + c], input in bit-reversed
-// position order, output in natural order.  tw_step = (m/2) / (S/2): stride of this size's twiddles in the table.
-template <class Fr>
-__device__ __forceinline__ void lds_fft(uint4* lds, unsigned logS, uint32_t cols, const Fr* __restrict__ tw,
-                                        uint32_t tw_step) {
+// `cols` = 2^log_cols interleaved transforms of size 2^logS held in LDS as lds[pos * cols + c], input in bit-reversed
+// position order, output in natural order (decimation in time).  tw_step = (m/2) / (S/2): stride of this size's twiddles
+// in the table.  The stages run R at a time in registers (R = RMAX = 3 where the transform has lanes to spare): a work
+// item owns the 2^R elements base + t 2^s of one column, does the radix-2 stages s .. s+R-1 on them (twelve butterflies
+// and seven twiddles for R = 3) and writes them back -- one LDS round trip and one barrier per R stages.  In the first
+// round the twiddles of exponent zero are known at compile time and their products are skipped (5 products instead of
+// 12).  A last round of fewer stages finishes sizes whose log is not a multiple of R.
+template <class Fr, int R, bool FIRST>
+__device__ __forceinline__ void lds_fft_round(uint4* lds, unsigned logS, unsigned s, unsigned log_cols, const Fr* __restrict__ tw,
+                                              uint32_t tw_step) {
+  constexpr uint32_t E = 1u << R;
   const uint32_t S = 1u << logS;
-  const uint32_t work = (S >> 1) * cols;
-  for (unsigned s = 0; s < logS; s++) {
-    const uint32_t h = 1u << s;
-    for (uint32_t idx = threadIdx.x; idx < work; idx += blockDim.x) {
-      const uint32_t b = idx / cols, c = idx - b * cols;
-      const uint32_t j = b & (h - 1);
-      const uint32_t i0 = ((b >> s) << (s + 1)) + j;
-      const uint32_t p0 = i0 * cols + c, p1 = (i0 + h) * cols + c;
-      Fr x0 = lds_get<Fr>(lds, p0);
-      Fr x1 = lds_get<Fr>(lds, p1);
-      if (s != 0) {
-        Fr w = glob_get(tw + (size_t)j * ((S >> (s + 1)) * tw_step));
-        x1 = Fr::mul(x1, w);
+  const uint32_t items = (S >> R) << log_cols;
+  const uint32_t cmask = (1u << log_cols) - 1u;
+  for (uint32_t idx = threadIdx.x; idx < items; idx += blockDim.x) {
+    const uint32_t g = idx >> log_cols, c = idx & cmask;
+    const uint32_t j0 = g & ((1u << s) - 1u);
+    const uint32_t base = ((g >> s) << (s + R)) + j0;
+    Fr x[E];
+#pragma unroll
+    for (uint32_t t = 0; t < E; t++) x[t] = lds_get<Fr>(lds, ((base + (t << s)) << log_cols) + c);
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      // stage s + q: pairs (t, t + 2^q); twiddle exponent j = j0 + (t mod 2^q) 2^s, scaled by S / 2^(s+q+1)
+      const uint32_t unit = (S >> (s + q + 1)) * tw_step;
+#pragma unroll
+      for (uint32_t t = 0; t < E; t++) {
+        if (t & (1u << q)) continue;
+        const uint32_t lowt = t & ((1u << q) - 1u);
+        Fr b = x[t + (1u << q)];
+        if (!(FIRST && lowt == 0)) {  // FIRST: s == 0, so j0 == 0 and the exponent is lowt 2^s: zero when lowt is
+          const Fr w = glob_get(tw + (size_t)(j0 + (lowt << s)) * unit);
+          b = Fr::mul(b, w);
+        }
+        const Fr a = x[t];
+        x[t] = Fr::add(a, b);
+        x[t + (1u << q)] = Fr::sub(a, b);
       }
-      lds_put<Fr>(lds, p0, Fr::add(x0, x1));
-      lds_put<Fr>(lds, p1, Fr::sub(x0, x1));
     }
-    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < E; t++) lds_put<Fr>(lds, ((base + (t << s)) << log_cols) + c, x[t]);
   }
+  __syncthreads();
+}
+
+template <class Fr, int R>
+__device__ __forceinline__ void lds_fft_tail(uint4* lds, unsigned logS, unsigned s, unsigned log_cols, const Fr* __restrict__ tw,
+                                             uint32_t tw_step) {
+  // the last logS - s < R stages
+  if constexpr (R >= 3) {
+    if (logS - s == 2) lds_fft_round<Fr, 2, false>(lds, logS, s, log_cols, tw, tw_step);
+  }
+  if constexpr (R >= 2) {
+    if (logS - s == 1) lds_fft_round<Fr, 1, false>(lds, logS, s, log_cols, tw, tw_step);
+  }
+}
+
+template <class Fr, int RMAX>
+__device__ __forceinline__ void lds_fft(uint4* lds, unsigned logS, unsigned log_cols, const Fr* __restrict__ tw, uint32_t tw_step) {
+  if (logS == 0) return;
+  if (logS < (unsigned)RMAX) {  // the whole transform is shorter than one round
+    if (logS == 2) lds_fft_round<Fr, 2, true>(lds, logS, 0, log_cols, tw, tw_step);
+    else lds_fft_round<Fr, 1, true>(lds, logS, 0, log_cols, tw, tw_step);
+    return;
+  }
+  lds_fft_round<Fr, RMAX, true>(lds, logS, 0, log_cols, tw, tw_step);
+  unsigned s = RMAX;
+  for (; s + RMAX <= logS; s += RMAX) lds_fft_round<Fr, RMAX, false>(lds, logS, s, log_cols, tw, tw_step);
+  lds_fft_tail<Fr, RMAX>(lds, logS, s, log_cols, tw, tw_step);
 }
 
 ZG_HD uint32_t bitrev32(uint32_t x, unsigned bits) { return bits ? (__builtin_bitreverse32(x) >> (32 - bits)) : 0; }
 
-// pass A: grid = N2 / TC blocks
-template <class Fr, bool COSET_IN>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, NttTables<Fr> T, int inverse, uint32_t TC) {
+// Both passes move a tile between HBM and LDS with 2^RMAX elements per thread, all of a thread's loads in flight at once.
+// blockIdx.y selects the vector of a batch (the prover transforms its three evaluation vectors in one launch);
+// consecutive vectors are `vstride` elements apart.
+
+// pass A: grid = (N2 / TC, batch) blocks, TC = 2^log_tc adjacent columns per tile
+template <class Fr, bool COSET_IN, int RMAX>
+__global__ void __launch_bounds__(ntt_max_threads(RMAX)) k_ntt_pass_a(Fr* __restrict__ a, NttTables<Fr> T, int inverse, unsigned log_tc,
+                                                             size_t vstride) {
   extern __shared__ uint4 lds[];
-  const uint32_t N1 = 1u << T.log_n1, N2 = 1u << T.log_n2;
+  constexpr uint32_t PER = 1u << RMAX;
+  a += (size_t)blockIdx.y * vstride;
+  const uint32_t N2 = 1u << T.log_n2;
   const uint32_t half_m = (1u << T.log_m) >> 1;
   const Fr* tw = inverse ? T.tw_inv : T.tw;
-  const uint32_t c0 = blockIdx.x * TC;
-  const uint32_t total = N1 * TC;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const uint32_t j1 = idx / TC, c = idx - j1 * TC;
-    Fr x = glob_get(a + (size_t)j1 * N2 + c0 + c);
-    if (COSET_IN) x = Fr::mul(Fr::mul(x, glob_get(T.g_lo + c0 + c)), glob_get(T.g_hi + j1));
-    lds_put<Fr>(lds, bitrev32(j1, T.log_n1) * TC + c, x);
+  const uint32_t c0 = blockIdx.x << log_tc;
+  const uint32_t total = 1u << (T.log_n1 + log_tc);
+  const uint32_t cmask = (1u << log_tc) - 1u;
+  for (uint32_t i0 = threadIdx.x; i0 < total; i0 += PER * blockDim.x) {
+    Fr x[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t idx = i0 + k * blockDim.x;
+      if (idx < total) x[k] = glob_get(a + (size_t)(idx >> log_tc) * N2 + c0 + (idx & cmask));
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t idx = i0 + k * blockDim.x;
+      if (idx < total) {
+        const uint32_t j1 = idx >> log_tc, c = idx & cmask;
+        if (COSET_IN) x[k] = Fr::mul(Fr::mul(x[k], glob_get(T.g_lo + c0 + c)), glob_get(T.g_hi + j1));
+        lds_put<Fr>(lds, (bitrev32(j1, T.log_n1) << log_tc) + c, x[k]);
+      }
+    }
   }
   __syncthreads();
-  lds_fft<Fr>(lds, T.log_n1, TC, tw, N2);
+  lds_fft<Fr, RMAX>(lds, T.log_n1, log_tc, tw, N2);
   for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const uint32_t k1 = idx / TC, c = idx - k1 * TC;
+    const uint32_t k1 = idx >> log_tc, c = idx & cmask;
     Fr x = lds_get<Fr>(lds, idx);
     const uint32_t e = (c0 + c) * k1;  // < m
     if (e != 0 && N2 > 1) x = Fr::mul(x, tw_lookup(tw, e, half_m ? half_m : 1));
@@ -143,24 +209,37 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, 
   }
 }
 
-// pass B: grid = N1 / TR blocks.  OUT_MODE 0: none, 1: * m^-1, 2: * g^-k m^-1 (two-level tables)
-template <class Fr, int OUT_MODE>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const Fr* __restrict__ a, Fr* __restrict__ out, NttTables<Fr> T,
-                                                             int inverse, uint32_t TR) {
+// pass B: grid = (N1 / TR, batch) blocks, TR = 2^log_tr adjacent rows per tile.  OUT_MODE 0: none, 1: * m^-1,
+// 2: * g^-k m^-1 (two-level tables)
+template <class Fr, int OUT_MODE, int RMAX>
+__global__ void __launch_bounds__(ntt_max_threads(RMAX)) k_ntt_pass_b(const Fr* __restrict__ a, Fr* __restrict__ out, NttTables<Fr> T,
+                                                             int inverse, unsigned log_tr, size_t vstride) {
   extern __shared__ uint4 lds[];
+  constexpr uint32_t PER = 1u << RMAX;
+  a += (size_t)blockIdx.y * vstride;
+  out += (size_t)blockIdx.y * vstride;
   const uint32_t N1 = 1u << T.log_n1, N2 = 1u << T.log_n2;
   const Fr* tw = inverse ? T.tw_inv : T.tw;
-  const uint32_t r0 = blockIdx.x * TR;
-  const uint32_t total = N2 * TR;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const uint32_t r = idx / N2, j2 = idx - r * N2;
-    Fr x = glob_get(a + (size_t)(r0 + r) * N2 + j2);
-    lds_put<Fr>(lds, bitrev32(j2, T.log_n2) * TR + r, x);
+  const uint32_t r0 = blockIdx.x << log_tr;
+  const uint32_t total = 1u << (T.log_n2 + log_tr);
+  const uint32_t rmask = (1u << log_tr) - 1u;
+  for (uint32_t i0 = threadIdx.x; i0 < total; i0 += PER * blockDim.x) {
+    Fr x[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t idx = i0 + k * blockDim.x;
+      if (idx < total) x[k] = glob_get(a + (size_t)(r0 + (idx >> T.log_n2)) * N2 + (idx & (N2 - 1u)));
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t idx = i0 + k * blockDim.x;
+      if (idx < total) lds_put<Fr>(lds, (bitrev32(idx & (N2 - 1u), T.log_n2) << log_tr) + (idx >> T.log_n2), x[k]);
+    }
   }
   __syncthreads();
-  lds_fft<Fr>(lds, T.log_n2, TR, tw, N1);
+  lds_fft<Fr, RMAX>(lds, T.log_n2, log_tr, tw, N1);
   for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const uint32_t k2 = idx / TR, r = idx - k2 * TR;
+    const uint32_t k2 = idx >> log_tr, r = idx & rmask;
     Fr x = lds_get<Fr>(lds, idx);
     if (OUT_MODE == 1) x = Fr::mul(x, T.m_inv);
     if (OUT_MODE == 2) x = Fr::mul(Fr::mul(x, glob_get(T.gi_lo + r0 + r)), glob_get(T.gi_hi + k2));

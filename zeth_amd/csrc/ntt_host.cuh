@@ -1,6 +1,8 @@
 // Host driver for the Fr evaluation-domain transforms: per-(curve, log m) twiddle tables cached in the context
 // (the analogue of constructing a libfqfft::basic_radix2_domain<Fr>(m) once), launch geometry, fused scalings.
 #pragma once
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "common.cuh"
@@ -142,45 +144,75 @@ int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) 
   return ZG_OK;
 }
 
-// data (m elements, Montgomery form) is overwritten with pass A's intermediate; the transform lands in `out`.
-template <class Fr>
-int ntt_launch(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset) {
+inline unsigned ilog2_u32(uint32_t x) {
+  unsigned l = 0;
+  while ((1u << (l + 1)) <= x && l < 31) l++;
+  return l;
+}
+
+template <class Fr, int RMAX>
+int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset, unsigned batch, size_t vstride) {
   static std::once_flag attr_once;  // clones of a key prove from several threads (zg_pk_clone)
   hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
     const int lim = NTT_LDS_ELEMS * 32;
-    const void* kernels[] = {(const void*)k_ntt_pass_a<Fr, false>, (const void*)k_ntt_pass_a<Fr, true>, (const void*)k_ntt_pass_b<Fr, 0>,
-                             (const void*)k_ntt_pass_b<Fr, 1>, (const void*)k_ntt_pass_b<Fr, 2>};
+    const void* kernels[] = {(const void*)k_ntt_pass_a<Fr, false, RMAX>, (const void*)k_ntt_pass_a<Fr, true, RMAX>,
+                             (const void*)k_ntt_pass_b<Fr, 0, RMAX>, (const void*)k_ntt_pass_b<Fr, 1, RMAX>,
+                             (const void*)k_ntt_pass_b<Fr, 2, RMAX>};
     for (const void* k : kernels)
       if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   });
   ZG_HIP(attr_err);
   const uint32_t N1 = 1u << D->T.log_n1, N2 = 1u << D->T.log_n2;
   const uint32_t TC = D->TC, TR = D->TR;
+  const unsigned log_tc = ilog2_u32(TC), log_tr = ilog2_u32(TR);
   hipStream_t st = ctx->stream;
   const size_t lds_a = (size_t)N1 * TC * 32, lds_b = (size_t)N2 * TR * 32;
   auto threads = [](uint32_t elems) {
-    uint32_t t = elems / 2;
+    uint32_t t = elems >> RMAX;  // lds_fft: 2^RMAX elements per work item
     if (t < 64) t = 64;
-    if (t > (uint32_t)NTT_THREADS) t = NTT_THREADS;
+    if (t > (uint32_t)ntt_max_threads(RMAX)) t = ntt_max_threads(RMAX);
     return t;
   };
   ctx->mark("ntt_pass_a");
+  const dim3 ga(N2 / TC, batch), ta(threads(N1 * TC));
   if (coset && !inverse)
-    hipLaunchKernelGGL((k_ntt_pass_a<Fr, true>), dim3(N2 / TC), dim3(threads(N1 * TC)), lds_a, st, data, D->T, inverse, TC);
+    hipLaunchKernelGGL((k_ntt_pass_a<Fr, true, RMAX>), ga, ta, lds_a, st, data, D->T, inverse, log_tc, vstride);
   else
-    hipLaunchKernelGGL((k_ntt_pass_a<Fr, false>), dim3(N2 / TC), dim3(threads(N1 * TC)), lds_a, st, data, D->T, inverse, TC);
+    hipLaunchKernelGGL((k_ntt_pass_a<Fr, false, RMAX>), ga, ta, lds_a, st, data, D->T, inverse, log_tc, vstride);
   ctx->mark("ntt_pass_b");
-  const dim3 gb(N1 / TR), tb(threads(N2 * TR));
+  const dim3 gb(N1 / TR, batch), tb(threads(N2 * TR));
   if (!inverse)
-    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 0>), gb, tb, lds_b, st, data, out, D->T, inverse, TR);
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 0, RMAX>), gb, tb, lds_b, st, data, out, D->T, inverse, log_tr, vstride);
   else if (!coset)
-    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 1>), gb, tb, lds_b, st, data, out, D->T, inverse, TR);
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 1, RMAX>), gb, tb, lds_b, st, data, out, D->T, inverse, log_tr, vstride);
   else
-    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 2>), gb, tb, lds_b, st, data, out, D->T, inverse, TR);
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 2, RMAX>), gb, tb, lds_b, st, data, out, D->T, inverse, log_tr, vstride);
   ctx->mark("ntt_end");
   ZG_HIP(hipGetLastError());
   return ZG_OK;
+}
+
+// Stages per register round for `batch` vectors of m elements.  Measured on MI355X (profiles/r2_ntt_radix.txt): the
+// transforms are bound by the field multiplier, not by LDS round trips, so the radix moves the time by a few percent
+// only -- radix 4 is best from 2^18 elements up, radix 2 below (a radix-4 work item leaves a small transform with too
+// few lanes), radix 8 never (150 VGPRs, half the waves).  ZG_NTT_RADIX_LOG = 1 | 2 overrides (tuning knob).
+inline int ntt_pick_rmax(size_t total_elems) {
+  static const int forced = [] {
+    const char* e = getenv("ZG_NTT_RADIX_LOG");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced >= 1 && forced <= 2) return forced;
+  return total_elems >= ((size_t)1 << 18) ? 2 : 1;
+}
+
+// data (`batch` vectors of m elements, `vstride` elements apart, Montgomery form) is overwritten with pass A's
+// intermediate; the transforms land in `out` (same layout).
+template <class Fr>
+int ntt_launch(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset, unsigned batch = 1, size_t vstride = 0) {
+  const int r = ntt_pick_rmax(((size_t)batch) << D->T.log_m);
+  if (r == 2) return ntt_launch_r<Fr, 2>(ctx, D, data, out, inverse, coset, batch, vstride);
+  return ntt_launch_r<Fr, 1>(ctx, D, data, out, inverse, coset, batch, vstride);
 }
 
 // C-ABI level: in-place semantics on `data` (device pointer, Montgomery or plain per `form`)

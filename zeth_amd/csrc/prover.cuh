@@ -47,15 +47,25 @@ __global__ void __launch_bounds__(256) k_build_w(const Fr* __restrict__ primary,
   glob_put(w_full + i, x);
 }
 
-// out[i] = <row_i, w> for i < nc; matrix A additionally carries w_0..w_num_inputs in rows nc..nc+num_inputs
-// (libsnark r1cs_to_qap: the extra constraints that make the A polynomials linearly independent); the rest of
-// the m-sized vector is zero.
+// The three constraint matrices of a key, evaluated by ONE launch (blockIdx.y picks the matrix).
+struct SpmvMatrices {
+  const uint64_t* row_ptr[3];
+  const uint32_t* col[3];
+  const void* val[3];
+};
+
+// out[k m + i] = <row_i of matrix k, w> for i < nc; matrix A (k = 0) additionally carries w_0..w_num_inputs in rows
+// nc..nc+num_inputs (libsnark r1cs_to_qap: the extra constraints that make the A polynomials linearly independent);
+// the rest of each m-sized vector is zero.
 template <class Fr>
-__global__ void __launch_bounds__(256) k_spmv(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                               const Fr* __restrict__ val, const Fr* __restrict__ w, size_t nc, size_t m,
-                                               size_t extra_rows, Fr* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_spmv(SpmvMatrices M, const Fr* __restrict__ w, size_t nc, size_t m, size_t extra_rows,
+                                               Fr* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
+  const unsigned k = blockIdx.y;
+  const uint64_t* __restrict__ row_ptr = M.row_ptr[k];
+  const uint32_t* __restrict__ col = M.col[k];
+  const Fr* __restrict__ val = static_cast<const Fr*>(M.val[k]);
   Fr acc = Fr::zero();
   if (i < nc) {
     // most coefficients of a boolean-heavy circuit are +1 or -1: those terms need no multiplication
@@ -67,10 +77,10 @@ __global__ void __launch_bounds__(256) k_spmv(const uint64_t* __restrict__ row_p
       else if (v == minus_one) acc = Fr::sub(acc, x);
       else acc = Fr::add(acc, Fr::mul(v, x));
     }
-  } else if (i - nc < extra_rows) {
+  } else if (k == 0 && i - nc < extra_rows) {
     acc = glob_get(w + (i - nc));
   }
-  glob_put(out + i, acc);
+  glob_put(out + (size_t)k * m + i, acc);
 }
 
 template <class Fr>
@@ -128,7 +138,7 @@ struct ProvingKeyDev : PkBase {
       }
       hipFree(A); hipFree(B1); hipFree(B2); hipFree(H); hipFree(L); hipFree(B_idx);
     }
-    hipFree(w); hipFree(ev[0]); hipFree(ev[1]); hipFree(ev[2]); hipFree(tmp); hipFree(bsc); hipFree(assign);
+    hipFree(w); hipFree(ev[0]); hipFree(tmp); hipFree(bsc); hipFree(assign);
   }
 
   template <class T>
@@ -253,8 +263,12 @@ struct ProvingKeyDev : PkBase {
     }  // equal priority: strict priorities starve the lanes
     ZG_HIP(hipEventCreateWithFlags(&w_ready, hipEventDisableTiming));
     ZG_HIP(hipMalloc((void**)&w, (num_vars + 1) * sizeof(Fr)));
-    for (int k = 0; k < 3; k++) ZG_HIP(hipMalloc((void**)&ev[k], m * sizeof(Fr)));
-    ZG_HIP(hipMalloc((void**)&tmp, m * sizeof(Fr)));
+    // the three evaluation vectors are one allocation, m elements apart, and so is the transform buffer: the transforms
+    // of all three run as one batched launch
+    ZG_HIP(hipMalloc((void**)&ev[0], 3 * m * sizeof(Fr)));
+    ev[1] = ev[0] + m;
+    ev[2] = ev[1] + m;
+    ZG_HIP(hipMalloc((void**)&tmp, 3 * m * sizeof(Fr)));
     ZG_HIP(hipMalloc((void**)&bsc, (B_len ? B_len : 1) * sizeof(Fr)));
     ZG_HIP(hipMalloc((void**)&assign, (num_vars ? num_vars : 1) * sizeof(Fr)));
     // 1 / Z(g) = 1 / (g^m - 1)   (divide_by_Z_on_coset)
@@ -310,15 +324,17 @@ struct ProvingKeyDev : PkBase {
   int qap_h() {
     hipStream_t st = ctx->stream;
     const unsigned mb = (unsigned)((m + 255) / 256);
-    for (int k = 0; k < 3; k++)
-      hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb), dim3(256), 0, st, mat[k].row_ptr, mat[k].col, (const Fr*)mat[k].val, w, nc, m,
-                         k == 0 ? num_inputs + 1 : (size_t)0, ev[k]);
+    SpmvMatrices M;
+    for (int k = 0; k < 3; k++) {
+      M.row_ptr[k] = mat[k].row_ptr;
+      M.col[k] = mat[k].col;
+      M.val[k] = mat[k].val;
+    }
+    hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb, 3), dim3(256), 0, st, M, (const Fr*)w, nc, m, num_inputs + 1, ev[0]);
     NttDomain<Fr>* D = nullptr;
     ZG_TRY(ntt_get_domain<Fr>(ctx, curve, log_m, &D));
-    for (int k = 0; k < 3; k++) {
-      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[k], tmp, 1, 0));  // iFFT
-      ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[k], 0, 1));  // cosetFFT
-    }
+    ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 0, 3, m));  // iFFT of A, B, C
+    ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[0], 0, 1, 3, m));  // cosetFFT of A, B, C
     hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
     ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
     ZG_HIP(hipGetLastError());
