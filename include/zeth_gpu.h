@@ -137,7 +137,7 @@ int zg_ntt(zg_ctx* ctx, int curve, void* data, unsigned log_n, int inverse, int 
 /* zg_ntt on device memory (d_data: 2^log_n Fr elements in HBM, transformed in place) for callers that cannot allocate:
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
  * It calls no hipMalloc / hipFree / allocating routine: the domain's twiddle and coset tables and the transform buffer
- * live in a static device array of 4,227,072 bytes that every GPU the library runs on holds until the process ends.
+ * live in a static device array of 4,254,720 bytes that every GPU the library runs on holds until the process ends.
  * Limit: log_n <= 16 (ZG_ERR_UNSUPPORTED beyond).  All calls on one GPU share that array (whatever their context), so
  * calls that overlap on one GPU race; the array keeps the last call's tables and rebuilds them, with kernels only, when
  * another (curve, log_n) is asked for.  Results are those of zg_ntt. */

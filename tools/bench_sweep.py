@@ -71,10 +71,10 @@ def ntt_case(ctx, cid, lg, reps=5):
         for _ in range(reps):
             run(inv, coset)
             ph = dict(ctx.last_timings())
-            ks.append(ph["ntt_pass_a"] + ph["ntt_pass_b"])
+            ks.append((ph["ntt_pass_a"] + ph["ntt_pass_b"], ph["ntt_pass_a"], ph["ntt_pass_b"]))
         ks.sort()
-        k_ms = ks[len(ks) // 2]
-        out = {"op": "ntt", "variant": name, "curve": C.name, "log_m": lg, "kernels_ms": k_ms,
+        k_ms, a_ms, b_ms = ks[len(ks) // 2]
+        out = {"op": "ntt", "variant": name, "curve": C.name, "log_m": lg, "kernels_ms": k_ms, "pass_a_ms": a_ms, "pass_b_ms": b_ms,
                "hbm_algorithmic_GBps": 128.0 * m / (k_ms * 1e-3) / 1e9, "hbm_frac": 128.0 * m / (k_ms * 1e-3) / 8e12,
                "mac_frac": (m / 2) * lg * 136 / (k_ms * 1e-3) / PEAK,
                "note": "two passes, each reads and writes the vector once: 128*m bytes; (m/2) log2(m) butterflies x 136 MAC"}
@@ -103,6 +103,8 @@ def main():
         msm_case(ctx, 0, 2, 22)
         msm_case(ctx, 1, 1, 22)
         msm_case(ctx, 1, 2, 20)
+    if which == "ntt1":  # one size, for profiling: ntt1 LOG_M [REPS]
+        ntt_case(ctx, 0, int(sys.argv[2]), reps=int(sys.argv[3]) if len(sys.argv) > 3 else 5)
     if which in ("all", "ntt"):
         for lg in (16, 19, 22, 24):
             ntt_case(ctx, 0, lg)

@@ -16,7 +16,8 @@
 // (curve, log n <= 16) domain followed by the 2^16-element transform buffer (ntt_host.cuh, ntt_static_bytes()).
 // `scratch` is a host-side stand-in for the symbol, never a device address: every use below goes through the pointer
 // hipGetSymbolAddress returned for the device in question.
-static constexpr size_t ZG_STATIC_SCRATCH_BYTES = (((size_t)1 << 16) + ((size_t)1 << 16) + 4 * 256) * 32;  // 4,227,072
+static constexpr size_t ZG_STATIC_SCRATCH_BYTES =
+    (((size_t)1 << 16) + 4 * 256 + ((3 * 256 * 36 + 31) / 32) + ((size_t)1 << 16)) * 32;  // 4,254,720
 static __device__ __align__(256) unsigned char scratch[ZG_STATIC_SCRATCH_BYTES];
 
 static constexpr int ZG_MAX_DEVICES = 64;

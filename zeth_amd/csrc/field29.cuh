@@ -1,4 +1,4 @@
-// Reduced-radix prime-field arithmetic for the bucket-accumulation kernel (gfx950).
+// Reduced-radix prime-field arithmetic for the bucket-accumulation kernel and the evaluation-domain transforms (gfx950).
 //
 // Why a second representation.  With full 32-bit limbs every 32x32 product fills its 64-bit result, so the sums of a
 // Montgomery product need one carry instruction per multiply (mont_asm.h: 306 instructions for the 136 products of an
@@ -21,7 +21,7 @@
 // (below 2^SHIFT p) for free.  pack() multiplies by R mod p the Montgomery way (x R' -> x R), reduces to [0, p) and
 // writes 32-bit limbs.
 //
-// Replaces (inside k_accum only) the same libff Fp_model arithmetic field.cuh restates; results are the same field
+// Replaces (inside k_accum and the transforms' butterflies) the same libff Fp_model arithmetic field.cuh restates; results are the same field
 // elements, so every MSM output stays bit-identical (tests/test_gpu_msm*.py, tests/test_field29.py).
 #pragma once
 #include <stdint.h>
@@ -40,6 +40,15 @@ struct Radix<Bn254FqParams> {
 template <>
 struct Radix<Bls377FqParams> {
   static constexpr int NL = 14, B = 28;
+};
+// the scalar fields (evaluation-domain transforms, ntt.cuh): 254 and 253 bits
+template <>
+struct Radix<Bn254FrParams> {
+  static constexpr int NL = 9, B = 29;
+};
+template <>
+struct Radix<Bls377FrParams> {
+  static constexpr int NL = 9, B = 29;
 };
 
 template <class P>
@@ -309,26 +318,39 @@ ZG_HD E29<P, 2, K29<P>::LNORM> sqr(const E29<P, VA, LA>& a) {
 }
 
 // ---- conversions to and from the stored form (32-bit limbs, Montgomery R = 2^(32 N)) ----------------------------
-// stored x R  ->  x R' = (x R) 2^SHIFT, read as limbs of the shifted bit string; value < 2^SHIFT p, limbs normalised
-template <class P>
-ZG_HD E29<P, (1ull << K29<P>::SHIFT), K29<P>::LNORM> unpack(const Fp<P>& s) {
+// the stored integer shifted left by SH bits, read as limbs; value < 2^SH p (the stored integer is below p), limbs
+// normalised
+template <int SH, class P>
+ZG_HD E29<P, (1ull << SH), K29<P>::LNORM> unpack_shifted(const Fp<P>& s) {
   using K = K29<P>;
-  E29<P, (1ull << K::SHIFT), K::LNORM> r;
+  static_assert(SH >= 0 && SH <= K::SHIFT, "unpack: the shifted value must fit the limbs");
+  E29<P, (1ull << SH), K::LNORM> r;
 #pragma unroll
   for (int i = 0; i < K::NL; i++) {
-    const int bit = i * K::B - K::SHIFT;  // first bit of limb i in the stored integer (negative: zeros shifted in)
+    const int bit = i * K::B - SH;  // first bit of limb i in the stored integer (negative: zeros shifted in)
     uint32_t w;
     if (bit < 0) {
       w = s.v[0] << (-bit);
     } else {
       const int q = bit / 32, sh = bit % 32;
-      const uint32_t lo = s.v[q];
+      const uint32_t lo = q < K::N ? s.v[q] : 0u;
       const uint32_t hi = q + 1 < K::N ? s.v[q + 1] : 0u;
       w = sh ? (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) : lo;
     }
     r.v[i] = w & K::MASK;
   }
   return r;
+}
+// stored x R  ->  x R' = (x R) 2^SHIFT: value < 2^SHIFT p
+template <class P>
+ZG_HD auto unpack(const Fp<P>& s) {
+  return unpack_shifted<K29<P>::SHIFT>(s);
+}
+// the stored integer as it is (x R read as a value of this form: mul(y R', unpack_raw(x R)) = y x R, the stored form of
+// the product); value < p
+template <class P>
+ZG_HD auto unpack_raw(const Fp<P>& s) {
+  return unpack_shifted<0>(s);
 }
 
 // R mod p (plain; the factor that takes x R' back to x R through mul()) and R' mod p (the Montgomery one of this form)
@@ -407,11 +429,10 @@ ZG_HD E29<P, 0, 0> zero() {
   return r;
 }
 
-// x R' (any value the Montgomery bound admits against 1 p) -> stored x R in [0, p)
-template <class P, uint64_t VA, uint64_t LA>
-ZG_HD Fp<P> pack(const E29<P, VA, LA>& a) {
+// t < 2 p with normalised limbs -> the representative in [0, p)
+template <class P>
+ZG_HD E29<P, 1, K29<P>::LNORM> canon(const E29<P, 2, K29<P>::LNORM>& t) {
   using K = K29<P>;
-  const auto t = mul(a, r_conv<P>());  // < 2 p, normalised
   // d = t - p with a borrow chain on B-bit limbs; keep t when it borrows
   uint32_t d[K::NL];
   int32_t br = 0;
@@ -427,9 +448,39 @@ ZG_HD Fp<P> pack(const E29<P, VA, LA>& a) {
     }
   }
   const uint32_t keep = (uint32_t)br;  // all ones when t < p
+  E29<P, 1, K::LNORM> r;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) r.v[i] = (t.v[i] & keep) | (d[i] & ~keep);
+  return r;
+}
+
+// -a for a in [0, p): p - a, or 0
+template <class P>
+ZG_HD E29<P, 1, K29<P>::LNORM> neg_canon(const E29<P, 1, K29<P>::LNORM>& a) {
+  using K = K29<P>;
+  uint32_t nz = 0;
+  E29<P, 1, K::LNORM> r;
+  int32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) {
+    nz |= a.v[i];
+    const int32_t x = (int32_t)K::PL.v[i] - (int32_t)a.v[i] + br;
+    r.v[i] = i < K::NL - 1 ? ((uint32_t)x & K::MASK) : (uint32_t)x;
+    br = x >> K::B;
+  }
+  const uint32_t m = nz ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) r.v[i] &= m;
+  return r;
+}
+
+// a value in [0, p) as the 32-bit words of the stored form
+template <class P>
+ZG_HD Fp<P> to_words(const E29<P, 1, K29<P>::LNORM>& a) {
+  using K = K29<P>;
   uint32_t l[K::NL + 1];
 #pragma unroll
-  for (int i = 0; i < K::NL; i++) l[i] = (t.v[i] & keep) | (d[i] & ~keep);
+  for (int i = 0; i < K::NL; i++) l[i] = a.v[i];
   l[K::NL] = 0;
   Fp<P> r;
 #pragma unroll
@@ -441,6 +492,22 @@ ZG_HD Fp<P> pack(const E29<P, VA, LA>& a) {
     if (q + 2 <= K::NL && 2 * K::B - sh < 32) w |= (uint64_t)l[q + 2] << (2 * K::B - sh);
     r.v[j] = (uint32_t)w;
   }
+  return r;
+}
+
+// x R' (any value the Montgomery bound admits against 1 p) -> stored x R in [0, p)
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD Fp<P> pack(const E29<P, VA, LA>& a) {
+  return to_words(canon(mul(a, r_conv<P>())));
+}
+
+// The same limbs under narrower static bounds that the CALLER has established by an argument the types cannot carry
+// (ntt.cuh: a bound that grows with the number of stages already run); every use states that argument.
+template <uint64_t VB, uint64_t LB, class P, uint64_t VA, uint64_t LA>
+ZG_HD E29<P, VB, LB> assume_bounds(const E29<P, VA, LA>& a) {
+  E29<P, VB, LB> r;
+#pragma unroll
+  for (int i = 0; i < K29<P>::NL; i++) r.v[i] = a.v[i];
   return r;
 }
 

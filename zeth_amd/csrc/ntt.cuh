@@ -8,59 +8,58 @@
 // natural order in, natural order out, exact field arithmetic, so outputs are bit-identical to any correct FFT.
 //
 // Structure: a two-pass "four-step" decomposition m = N1 * N2.  Each pass keeps its sub-transforms resident in
-// LDS (up to 4096 elements = 128 KB per workgroup) and runs all of their radix-2 stages there:
+// LDS (up to 4096 elements per workgroup) and runs all of their radix-2 stages there:
 //   pass A  tiles of TC adjacent columns: N1-point transforms down the columns (stride-N2 loads of TC*32-byte
 //           runs), then the inter-pass twiddle w^(j2 k1), written back in place
 //   pass B  tiles of TR adjacent rows: N2-point transforms along contiguous rows, fused output scaling
 //           (m^-1 and/or g^-k), written transposed (TR*32-byte runs) to the output buffer
 // Coset pre-scaling g^j is fused into pass A's load through two small tables g^(j1 N2), g^(j2).
+//
+// Arithmetic.  The transforms are bound by the field multiplier (profiles/r2_ntt_radix.txt: the time does not move with
+// the number of LDS round trips), so between the load and the store of a pass the elements live in the reduced-radix
+// form of field29.cuh: nine 29-bit limbs (36 bytes in LDS), Montgomery radix R' = 2^261.  A butterfly is one product
+// b w (column accumulators, no carry instructions), a limb-wise a + bw and a limb-wise a - bw + 3p: no carry chains and
+// no conditional subtractions.  Values are lazy: the bound grows by 3p per stage (a stage's "a" input is never
+// multiplied) from 32p at the load, which stays below the 168p (alt_bn128; 438p BLS12-377) the multiplier admits over
+// the 12 stages a pass can have -- checked at compile time, see Ntt29.  Conversions cost nothing extra: the load reads
+// the stored x R shifted left by 5 bits (= x R'), and the product every element receives on its way out anyway (the
+// inter-pass twiddle, m^-1, the coset factor, or R mod p when there is none) is taken against the STORED form of that
+// factor, which lands the result in the stored form x R again.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "field.cuh"
+#include "field29.cuh"
 
 namespace zg {
 
-static constexpr int NTT_LDS_ELEMS = 4096;  // 128 KB of 32-byte elements
+static constexpr int NTT_LDS_ELEMS = 4096;  // 144 KB of 36-byte elements
 static constexpr int NTT_THREADS = 1024;
-// most threads of a workgroup whose rounds take RMAX stages: a work item of 2^RMAX elements per thread, and registers
-// for them (radix 8: ~150 VGPRs, so at most 512 threads)
-constexpr int ntt_max_threads(int rmax) { return rmax >= 3 ? 512 : 1024; }
+static constexpr int NTT_MAX_STAGES = 12;   // log2 NTT_LDS_ELEMS: the stages one pass can run
+constexpr int ntt_max_threads(int) { return NTT_THREADS; }
 
 template <class Fr>
 struct NttTables {
   unsigned log_m;
-  const Fr* tw;      // w^i, i < m/2 (forward) -- Montgomery form
+  const Fr* tw;      // w^i, i < m/2 (forward) -- stored (Montgomery R) form: the inter-pass twiddles
   const Fr* tw_inv;  // w^-i
   // two-level coset tables, N1 + N2 entries each
-  const Fr* g_hi;    // g^(j1 N2), j1 < N1      (input scaling of cosetFFT)
+  const Fr* g_hi;    // g^(j1 N2), j1 < N1      (input scaling of cosetFFT; the kernels read g_hi29)
   const Fr* g_lo;    // g^(j2), j2 < N2
   const Fr* gi_lo;   // g^(-k1) * m^-1, k1 < N1  (output scaling of icosetFFT)
   const Fr* gi_hi;   // g^(-N1 k2), k2 < N2
+  // the butterflies' twiddles and g_hi in the reduced-radix form: 9 words per entry, x R' mod p in [0, p).  One compact
+  // table per pass and direction -- (w^N2)^j, j < N1/2 for pass A and (w^N1)^j, j < N2/2 for pass B -- so that the
+  // entries a workgroup gathers are neighbours in memory (36 KB for a 2048-point pass) instead of a stride apart
+  const uint32_t* twa29;
+  const uint32_t* twa_inv29;
+  const uint32_t* twb29;
+  const uint32_t* twb_inv29;
+  const uint32_t* g_hi29;
   Fr m_inv;
   unsigned log_n1, log_n2;
 };
 
-template <class Fr>
-ZG_HD Fr lds_get(const uint4* lds, uint32_t pos) {
-  union {
-    uint4 q[2];
-    Fr f;
-  } u;
-  u.q[0] = lds[2 * pos];
-  u.q[1] = lds[2 * pos + 1];
-  return u.f;
-}
-template <class Fr>
-ZG_HD void lds_put(uint4* lds, uint32_t pos, const Fr& f) {
-  union {
-    uint4 q[2];
-    Fr f;
-  } u;
-  u.f = f;
-  lds[2 * pos] = u.q[0];
-  lds[2 * pos + 1] = u.q[1];
-}
 template <class Fr>
 ZG_HD Fr glob_get(const Fr* p) {
   union {
@@ -84,23 +83,88 @@ ZG_HD void glob_put(Fr* p, const Fr& f) {
   d[1] = u.q[1];
 }
 
-// w^e for e < m from the half table: w^(e) = -w^(e - m/2) for e >= m/2
+// Types and bounds of the reduced-radix transform.  An element in LDS is typed XL: value < VW p, limbs <= LL.
+//   load            value < V0 p = 32 p (unpack), or < 2 p behind the coset products
+//   first round     its first stage has only unit twiddles and skips the products: a + b < 64 p, a - b + 33 p < 65 p;
+//                   its second stage (radix 4) multiplies every pair (unit twiddles by the constant one): + 3 p
+//   later stages    + 3 p each (b w < 2 p: a + bw, a - bw + 3 p)
+// so the input of the round that starts at stage s is below VFIRST + 3 (s - 1) p <= VW p, and the output of the last
+// round below VE p.  A round is compiled ONCE, for an input of type XL, and proves that its output is within
+// XL::vb + 3 R; narrowing that back to XL (assume_bounds) is justified by the count above -- at most NTT_MAX_STAGES
+// stages -- which the static_asserts here tie to the multiplier's bound.
 template <class Fr>
-ZG_HD Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t half_m) {
-  Fr w = glob_get(tw + (e & (half_m - 1)));
-  return (e & half_m) ? Fr::neg(w) : w;
+struct Ntt29 {
+  using P = typename Fr::Params;
+  using K = K29<P>;
+  static constexpr int NL = K::NL;
+  static constexpr uint64_t V0 = 1ull << K::SHIFT;
+  static constexpr uint64_t VFIRST = 2 * V0 + 1 + 3;
+  static constexpr uint64_t VW = VFIRST + 3 * (NTT_MAX_STAGES - 1);
+  static constexpr uint64_t VE = VW + 3 * 2;
+  static constexpr uint64_t LL = K::LNORM + 5;
+  static_assert(VE <= K::mont_room(), "a pass of 12 stages would leave the multiplier's bound");
+  using W = E29<P, 1, K::LNORM>;    // a twiddle: canonical
+  using X0 = E29<P, V0, K::LNORM>;  // fresh from unpack
+  using XL = E29<P, VW, LL>;        // in LDS between rounds
+  using XE = E29<P, VE, LL>;        // in LDS after the last round
+};
+
+// An element is 9 words, so two positions share their banks exactly when they are a multiple of 64 apart -- which the
+// bit-reversed scatter of the load and the first rounds' strides produce all the time.  Position p therefore lives in
+// slot p + p / 64: positions 64 k apart land 65 k apart (64 extra slots for 4096 elements).
+static constexpr int NTT_LDS_SLOTS = NTT_LDS_ELEMS + NTT_LDS_ELEMS / 64;
+__device__ __forceinline__ uint32_t lds_slot(uint32_t pos) { return pos + (pos >> 6); }
+
+template <class X>
+__device__ __forceinline__ X lds_get29(const uint32_t* lds, uint32_t pos) {
+  X x;
+  const uint32_t* p = lds + lds_slot(pos) * (uint32_t)X::K::NL;
+#pragma unroll
+  for (int i = 0; i < X::K::NL; i++) x.v[i] = p[i];
+  return x;
+}
+template <class X>
+__device__ __forceinline__ void lds_put29(uint32_t* lds, uint32_t pos, const X& x) {
+  uint32_t* p = lds + lds_slot(pos) * (uint32_t)X::K::NL;
+#pragma unroll
+  for (int i = 0; i < X::K::NL; i++) p[i] = x.v[i];
+}
+template <class Fr>
+__device__ __forceinline__ typename Ntt29<Fr>::W tw_get29(const uint32_t* __restrict__ t, size_t i) {
+  typename Ntt29<Fr>::W w;
+  const uint32_t* p = t + i * (size_t)Ntt29<Fr>::NL;
+#pragma unroll
+  for (int k = 0; k < Ntt29<Fr>::NL; k++) w.v[k] = p[k];
+  return w;
+}
+
+// (a, b) -> (a + b w, a - b w), both under the difference's (wider) bounds
+template <class XA, class XB, class WT>
+__device__ __forceinline__ void bfly29(const XA& a, const XB& b, const WT& w, decltype(f29::sub(a, f29::mul(b, w)))& lo,
+                                       decltype(f29::sub(a, f29::mul(b, w)))& hi) {
+  using D = decltype(f29::sub(a, f29::mul(b, w)));
+  const auto t = f29::mul(b, w);
+  lo = f29::widen<D::vb, D::lmax>(f29::add(a, t));
+  hi = f29::sub(a, t);
+}
+// the same with w = 1 and no product
+template <class X>
+__device__ __forceinline__ void bfly29_unit(const X& a, const X& b, decltype(f29::sub(a, b))& lo, decltype(f29::sub(a, b))& hi) {
+  using D = decltype(f29::sub(a, b));
+  lo = f29::widen<D::vb, D::lmax>(f29::add(a, b));
+  hi = f29::sub(a, b);
 }
 
 // `cols` = 2^log_cols interleaved transforms of size 2^logS held in LDS as lds[pos * cols + c], input in bit-reversed
-// position order, output in natural order (decimation in time).  tw_step = (m/2) / (S/2): stride of this size's twiddles
-// in the table.  The stages run R at a time in registers (R = RMAX = 3 where the transform has lanes to spare): a work
-// item owns the 2^R elements base + t 2^s of one column, does the radix-2 stages s .. s+R-1 on them (twelve butterflies
-// and seven twiddles for R = 3) and writes them back -- one LDS round trip and one barrier per R stages.  In the first
-// round the twiddles of exponent zero are known at compile time and their products are skipped (5 products instead of
-// 12).  A last round of fewer stages finishes sizes whose log is not a multiple of R.
-template <class Fr, int R, bool FIRST>
-__device__ __forceinline__ void lds_fft_round(uint4* lds, unsigned logS, unsigned s, unsigned log_cols, const Fr* __restrict__ tw,
-                                              uint32_t tw_step) {
+// position order, output in natural order (decimation in time).  tw: this size's twiddles, S/2 entries.  The stages run R at a time in registers (R = 2 where the transform has lanes to spare): a work item owns
+// the 2^R elements base + t 2^s of one column, does the stages s .. s+R-1 on them and writes them back -- one LDS round
+// trip and one barrier per R stages.  XIN: the type of the elements this round finds in LDS (Ntt29).
+template <class Fr, int R, bool FIRST, class XIN>
+__device__ __forceinline__ void lds_fft_round(uint32_t* lds, unsigned logS, unsigned s, unsigned log_cols,
+                                              const uint32_t* __restrict__ tw) {
+  using N = Ntt29<Fr>;
+  using XL = typename N::XL;
+  static_assert(R == 1 || R == 2, "rounds of one or two stages");
   constexpr uint32_t E = 1u << R;
   const uint32_t S = 1u << logS;
   const uint32_t items = (S >> R) << log_cols;
@@ -109,57 +173,88 @@ __device__ __forceinline__ void lds_fft_round(uint4* lds, unsigned logS, unsigne
     const uint32_t g = idx >> log_cols, c = idx & cmask;
     const uint32_t j0 = g & ((1u << s) - 1u);
     const uint32_t base = ((g >> s) << (s + R)) + j0;
-    Fr x[E];
+    XIN x[E];
 #pragma unroll
-    for (uint32_t t = 0; t < E; t++) x[t] = lds_get<Fr>(lds, ((base + (t << s)) << log_cols) + c);
+    for (uint32_t t = 0; t < E; t++) x[t] = lds_get29<XIN>(lds, ((base + (t << s)) << log_cols) + c);
+    // stage s: pairs (t, t + 1), twiddle exponent j0 (zero in the first round: s == 0)
+    const uint32_t unit0 = S >> (s + 1);
+    if constexpr (FIRST) {
+      using D0 = decltype(f29::sub(x[0], x[0]));
+      D0 y[E];
 #pragma unroll
-    for (int q = 0; q < R; q++) {
-      // stage s + q: pairs (t, t + 2^q); twiddle exponent j = j0 + (t mod 2^q) 2^s, scaled by S / 2^(s+q+1)
-      const uint32_t unit = (S >> (s + q + 1)) * tw_step;
+      for (uint32_t t = 0; t < E; t += 2) bfly29_unit(x[t], x[t + 1], y[t], y[t + 1]);
+      if constexpr (R == 1) {
 #pragma unroll
-      for (uint32_t t = 0; t < E; t++) {
-        if (t & (1u << q)) continue;
-        const uint32_t lowt = t & ((1u << q) - 1u);
-        Fr b = x[t + (1u << q)];
-        if (!(FIRST && lowt == 0)) {  // FIRST: s == 0, so j0 == 0 and the exponent is lowt 2^s: zero when lowt is
-          const Fr w = glob_get(tw + (size_t)(j0 + (lowt << s)) * unit);
-          b = Fr::mul(b, w);
+        for (uint32_t t = 0; t < E; t++) {
+          const auto o = f29::carry(y[t]);
+          static_assert(decltype(o)::vb <= N::VFIRST && decltype(o)::lmax <= N::LL, "first round leaves its bounds");
+          lds_put29(lds, ((base + (t << s)) << log_cols) + c, f29::widen<XL::vb, XL::lmax>(o));
         }
-        const Fr a = x[t];
-        x[t] = Fr::add(a, b);
-        x[t + (1u << q)] = Fr::sub(a, b);
+      } else {
+        // stage 1: pairs (0, 2) with the unit twiddle -- multiplied all the same, to bring that element below 2 p --
+        // and (1, 3) with w^(S/4)
+        const uint32_t unit1 = S >> 2;
+        using D1 = decltype(f29::sub(y[0], f29::mul(y[0], f29::one<typename N::P>())));
+        D1 z[E];
+        bfly29(y[0], y[2], f29::one<typename N::P>(), z[0], z[2]);
+        bfly29(y[1], y[3], tw_get29<Fr>(tw, unit1), z[1], z[3]);
+#pragma unroll
+        for (uint32_t t = 0; t < E; t++) {
+          const auto o = f29::carry(z[t]);
+          static_assert(decltype(o)::vb <= N::VFIRST && decltype(o)::lmax <= N::LL, "first round leaves its bounds");
+          lds_put29(lds, ((base + (t << s)) << log_cols) + c, f29::widen<XL::vb, XL::lmax>(o));
+        }
+      }
+    } else {
+      using D0 = decltype(f29::sub(x[0], f29::mul(x[0], typename N::W{})));
+      D0 y[E];
+      const typename N::W w0 = tw_get29<Fr>(tw, (size_t)j0 * unit0);
+#pragma unroll
+      for (uint32_t t = 0; t < E; t += 2) bfly29(x[t], x[t + 1], w0, y[t], y[t + 1]);
+      if constexpr (R == 1) {
+#pragma unroll
+        for (uint32_t t = 0; t < E; t++) {
+          const auto o = f29::carry(y[t]);
+          static_assert(decltype(o)::vb <= XIN::vb + 3 * R && decltype(o)::lmax <= N::LL, "round grows by more than 3 p a stage");
+          // at most NTT_MAX_STAGES stages run in a pass: see Ntt29
+          lds_put29(lds, ((base + (t << s)) << log_cols) + c, f29::assume_bounds<XL::vb, XL::lmax>(o));
+        }
+      } else {
+        // stage s + 1: pairs (t, t + 2), exponent j0 + t 2^s, scaled by S / 2^(s+2)
+        const uint32_t unit1 = S >> (s + 2);
+        using D1 = decltype(f29::sub(y[0], f29::mul(y[0], typename N::W{})));
+        D1 z[E];
+        bfly29(y[0], y[2], tw_get29<Fr>(tw, (size_t)j0 * unit1), z[0], z[2]);
+        bfly29(y[1], y[3], tw_get29<Fr>(tw, (size_t)(j0 + (1u << s)) * unit1), z[1], z[3]);
+#pragma unroll
+        for (uint32_t t = 0; t < E; t++) {
+          const auto o = f29::carry(z[t]);
+          static_assert(decltype(o)::vb <= XIN::vb + 3 * R && decltype(o)::lmax <= N::LL, "round grows by more than 3 p a stage");
+          lds_put29(lds, ((base + (t << s)) << log_cols) + c, f29::assume_bounds<XL::vb, XL::lmax>(o));
+        }
       }
     }
-#pragma unroll
-    for (uint32_t t = 0; t < E; t++) lds_put<Fr>(lds, ((base + (t << s)) << log_cols) + c, x[t]);
   }
   __syncthreads();
 }
 
-template <class Fr, int R>
-__device__ __forceinline__ void lds_fft_tail(uint4* lds, unsigned logS, unsigned s, unsigned log_cols, const Fr* __restrict__ tw,
-                                             uint32_t tw_step) {
-  // the last logS - s < R stages
-  if constexpr (R >= 3) {
-    if (logS - s == 2) lds_fft_round<Fr, 2, false>(lds, logS, s, log_cols, tw, tw_step);
-  }
-  if constexpr (R >= 2) {
-    if (logS - s == 1) lds_fft_round<Fr, 1, false>(lds, logS, s, log_cols, tw, tw_step);
-  }
-}
-
+// V0IN: the elements the load left in LDS are below V0IN p (Ntt29::V0, or 2 behind the coset products)
 template <class Fr, int RMAX>
-__device__ __forceinline__ void lds_fft(uint4* lds, unsigned logS, unsigned log_cols, const Fr* __restrict__ tw, uint32_t tw_step) {
+__device__ __forceinline__ void lds_fft(uint32_t* lds, unsigned logS, unsigned log_cols, const uint32_t* __restrict__ tw) {
+  using N = Ntt29<Fr>;
+  using X0 = typename N::X0;
+  using XL = typename N::XL;
   if (logS == 0) return;
   if (logS < (unsigned)RMAX) {  // the whole transform is shorter than one round
-    if (logS == 2) lds_fft_round<Fr, 2, true>(lds, logS, 0, log_cols, tw, tw_step);
-    else lds_fft_round<Fr, 1, true>(lds, logS, 0, log_cols, tw, tw_step);
+    lds_fft_round<Fr, 1, true, X0>(lds, logS, 0, log_cols, tw);
     return;
   }
-  lds_fft_round<Fr, RMAX, true>(lds, logS, 0, log_cols, tw, tw_step);
+  lds_fft_round<Fr, RMAX, true, X0>(lds, logS, 0, log_cols, tw);
   unsigned s = RMAX;
-  for (; s + RMAX <= logS; s += RMAX) lds_fft_round<Fr, RMAX, false>(lds, logS, s, log_cols, tw, tw_step);
-  lds_fft_tail<Fr, RMAX>(lds, logS, s, log_cols, tw, tw_step);
+  for (; s + RMAX <= logS; s += RMAX) lds_fft_round<Fr, RMAX, false, XL>(lds, logS, s, log_cols, tw);
+  if constexpr (RMAX == 2) {
+    if (logS - s == 1) lds_fft_round<Fr, 1, false, XL>(lds, logS, s, log_cols, tw);
+  }
 }
 
 ZG_HD uint32_t bitrev32(uint32_t x, unsigned bits) { return bits ? (__builtin_bitreverse32(x) >> (32 - bits)) : 0; }
@@ -168,17 +263,31 @@ ZG_HD uint32_t bitrev32(uint32_t x, unsigned bits) { return bits ? (__builtin_bi
 // blockIdx.y selects the vector of a batch (the prover transforms its three evaluation vectors in one launch);
 // consecutive vectors are `vstride` elements apart.
 
+// Tiles narrower than a 128-byte line (4 elements) share their lines with the neighbouring tiles: pass A's column reads
+// and pass B's transposed writes then touch every line 4 / width times.  Workgroups are dealt to the 8 XCDs in turn
+// (block b runs on XCD b mod 8, each XCD with its own L2), so the tiles that share lines are given to blocks b, b + 8,
+// ... -- neighbours in time on ONE XCD, where the second touch is an L2 hit.
+__device__ __forceinline__ uint32_t ntt_tile_of_block(uint32_t b, uint32_t nblocks, unsigned log_width) {
+  if (log_width >= 2) return b;
+  const uint32_t share = 4u >> log_width;  // tiles per line: 2 or 4
+  if (nblocks % (8u * share)) return b;
+  const uint32_t xcd = b & 7u, slot = b >> 3;
+  return ((slot / share) * 8u + xcd) * share + (slot % share);
+}
+
 // pass A: grid = (N2 / TC, batch) blocks, TC = 2^log_tc adjacent columns per tile
 template <class Fr, bool COSET_IN, int RMAX>
-__global__ void __launch_bounds__(ntt_max_threads(RMAX)) k_ntt_pass_a(Fr* __restrict__ a, NttTables<Fr> T, int inverse, unsigned log_tc,
-                                                             size_t vstride) {
-  extern __shared__ uint4 lds[];
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, NttTables<Fr> T, int inverse, unsigned log_tc,
+                                                            size_t vstride) {
+  extern __shared__ uint32_t lds[];
+  using N = Ntt29<Fr>;
+  using P = typename N::P;
   constexpr uint32_t PER = 1u << RMAX;
   a += (size_t)blockIdx.y * vstride;
   const uint32_t N2 = 1u << T.log_n2;
-  const uint32_t half_m = (1u << T.log_m) >> 1;
   const Fr* tw = inverse ? T.tw_inv : T.tw;
-  const uint32_t c0 = blockIdx.x << log_tc;
+  const uint32_t* tw29 = inverse ? T.twa_inv29 : T.twa29;
+  const uint32_t c0 = ntt_tile_of_block(blockIdx.x, gridDim.x, log_tc) << log_tc;
   const uint32_t total = 1u << (T.log_n1 + log_tc);
   const uint32_t cmask = (1u << log_tc) - 1u;
   for (uint32_t i0 = threadIdx.x; i0 < total; i0 += PER * blockDim.x) {
@@ -193,34 +302,55 @@ __global__ void __launch_bounds__(ntt_max_threads(RMAX)) k_ntt_pass_a(Fr* __rest
       const uint32_t idx = i0 + k * blockDim.x;
       if (idx < total) {
         const uint32_t j1 = idx >> log_tc, c = idx & cmask;
-        if (COSET_IN) x[k] = Fr::mul(Fr::mul(x[k], glob_get(T.g_lo + c0 + c)), glob_get(T.g_hi + j1));
-        lds_put<Fr>(lds, (bitrev32(j1, T.log_n1) << log_tc) + c, x[k]);
+        const uint32_t pos = (bitrev32(j1, T.log_n1) << log_tc) + c;
+        if (COSET_IN) {
+          // x R' g_hi R' / R' = x g_hi R' (< 2 p), then against g_lo R' (< 32 p): x g R' < 2 p
+          const auto t = f29::mul(f29::unpack(x[k]), tw_get29<Fr>(T.g_hi29, j1));
+          const auto u = f29::mul(t, f29::unpack(glob_get(T.g_lo + c0 + c)));
+          lds_put29(lds, pos, f29::widen<N::X0::vb, N::X0::lmax>(u));
+        } else {
+          lds_put29(lds, pos, f29::unpack(x[k]));
+        }
       }
     }
   }
   __syncthreads();
-  lds_fft<Fr, RMAX>(lds, T.log_n1, log_tc, tw, N2);
+  lds_fft<Fr, RMAX>(lds, T.log_n1, log_tc, tw29);
   for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const uint32_t k1 = idx >> log_tc, c = idx & cmask;
-    Fr x = lds_get<Fr>(lds, idx);
+    const auto x = lds_get29<typename N::XE>(lds, idx);
     const uint32_t e = (c0 + c) * k1;  // < m
-    if (e != 0 && N2 > 1) x = Fr::mul(x, tw_lookup(tw, e, half_m ? half_m : 1));
-    glob_put(a + (size_t)k1 * N2 + c0 + c, x);
+    // The inter-pass twiddle w^e, e = e_hi N2 + e_lo, from two small tables instead of a gather over the m/2-entry one
+    // (one line of HBM traffic per element): x R' against (w^N2)^e_hi R' (pass A's own butterfly table; its upper half by
+    // sign), then against the STORED w^e_lo R, which lands the product in the stored form (R mod p when there is no
+    // twiddle).
+    typename N::W r;
+    if (e != 0 && N2 > 1) {
+      const uint32_t e_hi = e >> T.log_n2, e_lo = e & (N2 - 1u), hn1 = (1u << T.log_n1) >> 1;
+      const auto t = f29::mul(x, tw_get29<Fr>(tw29, e_hi & (hn1 - 1u)));
+      r = f29::canon(f29::mul(t, f29::unpack_raw(glob_get(tw + e_lo))));
+      if (e_hi & hn1) r = f29::neg_canon(r);  // (w^N2)^(N1/2) = -1
+    } else {
+      r = f29::canon(f29::mul(x, f29::r_conv<P>()));
+    }
+    glob_put(a + (size_t)k1 * N2 + c0 + c, f29::to_words(r));
   }
 }
 
 // pass B: grid = (N1 / TR, batch) blocks, TR = 2^log_tr adjacent rows per tile.  OUT_MODE 0: none, 1: * m^-1,
 // 2: * g^-k m^-1 (two-level tables)
 template <class Fr, int OUT_MODE, int RMAX>
-__global__ void __launch_bounds__(ntt_max_threads(RMAX)) k_ntt_pass_b(const Fr* __restrict__ a, Fr* __restrict__ out, NttTables<Fr> T,
-                                                             int inverse, unsigned log_tr, size_t vstride) {
-  extern __shared__ uint4 lds[];
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const Fr* __restrict__ a, Fr* __restrict__ out, NttTables<Fr> T,
+                                                            int inverse, unsigned log_tr, size_t vstride) {
+  extern __shared__ uint32_t lds[];
+  using N = Ntt29<Fr>;
+  using P = typename N::P;
   constexpr uint32_t PER = 1u << RMAX;
   a += (size_t)blockIdx.y * vstride;
   out += (size_t)blockIdx.y * vstride;
   const uint32_t N1 = 1u << T.log_n1, N2 = 1u << T.log_n2;
-  const Fr* tw = inverse ? T.tw_inv : T.tw;
-  const uint32_t r0 = blockIdx.x << log_tr;
+  const uint32_t* tw29 = inverse ? T.twb_inv29 : T.twb29;
+  const uint32_t r0 = ntt_tile_of_block(blockIdx.x, gridDim.x, log_tr) << log_tr;
   const uint32_t total = 1u << (T.log_n2 + log_tr);
   const uint32_t rmask = (1u << log_tr) - 1u;
   for (uint32_t i0 = threadIdx.x; i0 < total; i0 += PER * blockDim.x) {
@@ -233,18 +363,34 @@ __global__ void __launch_bounds__(ntt_max_threads(RMAX)) k_ntt_pass_b(const Fr* 
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
       const uint32_t idx = i0 + k * blockDim.x;
-      if (idx < total) lds_put<Fr>(lds, (bitrev32(idx & (N2 - 1u), T.log_n2) << log_tr) + (idx >> T.log_n2), x[k]);
+      if (idx < total) lds_put29(lds, (bitrev32(idx & (N2 - 1u), T.log_n2) << log_tr) + (idx >> T.log_n2), f29::unpack(x[k]));
     }
   }
   __syncthreads();
-  lds_fft<Fr, RMAX>(lds, T.log_n2, log_tr, tw, N1);
+  lds_fft<Fr, RMAX>(lds, T.log_n2, log_tr, tw29);
   for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const uint32_t k2 = idx >> log_tr, r = idx & rmask;
-    Fr x = lds_get<Fr>(lds, idx);
-    if (OUT_MODE == 1) x = Fr::mul(x, T.m_inv);
-    if (OUT_MODE == 2) x = Fr::mul(Fr::mul(x, glob_get(T.gi_lo + r0 + r)), glob_get(T.gi_hi + k2));
-    glob_put(out + (size_t)k2 * N1 + r0 + r, x);
+    const auto x = lds_get29<typename N::XE>(lds, idx);
+    typename N::W y;
+    if (OUT_MODE == 0) y = f29::canon(f29::mul(x, f29::r_conv<P>()));
+    if (OUT_MODE == 1) y = f29::canon(f29::mul(x, f29::unpack_raw(T.m_inv)));
+    if (OUT_MODE == 2)  // x R' against the stored gi_lo R: x gi_lo R (< 2 p); that against gi_hi R' (< 32 p): x gi R
+      y = f29::canon(f29::mul(f29::mul(x, f29::unpack_raw(glob_get(T.gi_lo + r0 + r))), f29::unpack(glob_get(T.gi_hi + k2))));
+    glob_put(out + (size_t)k2 * N1 + r0 + r, f29::to_words(y));
   }
+}
+
+// dst[9 i ..] = the reduced-radix form of src[i * stride]: x R' mod p in [0, p)
+template <class Fr>
+__global__ void __launch_bounds__(256) k_to_radix29(const Fr* __restrict__ src, uint32_t stride, uint32_t* __restrict__ dst,
+                                                    uint32_t count) {
+  using P = typename Fr::Params;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const auto w = f29::canon(f29::mul(f29::unpack(glob_get(src + (size_t)i * stride)), f29::one<P>()));
+  uint32_t* p = dst + (size_t)i * K29<P>::NL;
+#pragma unroll
+  for (int k = 0; k < K29<P>::NL; k++) p[k] = w.v[k];
 }
 
 // ---- table construction -------------------------------------------------------------------------

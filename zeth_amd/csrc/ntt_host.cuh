@@ -38,8 +38,16 @@ inline Fr host_pow_u64(Fr b, uint64_t e) {
   return r;
 }
 
+inline uint32_t ntt_tile_elems() {  // elements of a workgroup's tile; ZG_NTT_TILE_ELEMS = 2048 | 4096 (tuning knob)
+  static const uint32_t v = [] {
+    const char* e = getenv("ZG_NTT_TILE_ELEMS");
+    const uint32_t x = e ? (uint32_t)atoi(e) : 0u;
+    return (x == 2048u || x == 4096u) ? x : (uint32_t)NTT_LDS_ELEMS;
+  }();
+  return v;
+}
 inline uint32_t ntt_pick_tile(uint32_t n_this, uint32_t n_other) {
-  uint32_t t = NTT_LDS_ELEMS / n_this;
+  uint32_t t = (n_this <= ntt_tile_elems() ? ntt_tile_elems() : (uint32_t)NTT_LDS_ELEMS) / n_this;
   if (t > n_other) t = n_other;
   if (t < 1) t = 1;
   // keep at least ~512 workgroups in flight when the transform is large enough to allow it
@@ -54,12 +62,19 @@ inline bool ntt_split(unsigned log_m, unsigned* l1, unsigned* l2) {
   return *l1 <= 12;
 }
 
-// Fr elements of table storage a domain of 2^log_m points needs: w^i and w^-i (m/2 each), the four coset tables
+// Table storage of a domain of 2^log_m points, in 32-byte units (sizeof Fr): w^i and w^-i (m/2 each) and the four coset
+// tables in the stored form, then the per-pass butterfly twiddles and g_hi in the reduced-radix form (36 bytes an entry,
+// ntt.cuh)
+inline size_t ntt_table29_entries(unsigned log_m) {
+  unsigned l1 = 0, l2 = 0;
+  ntt_split(log_m, &l1, &l2);
+  return 2 * ((size_t)1 << l1) + ((size_t)1 << l2);  // twa and twa_inv (N1/2 each), twb and twb_inv (N2/2 each), g_hi (N1)
+}
 inline size_t ntt_table_elems(unsigned log_m) {
   unsigned l1 = 0, l2 = 0;
   ntt_split(log_m, &l1, &l2);
   const size_t m = (size_t)1 << log_m, half = m > 1 ? m / 2 : 1;
-  return 2 * half + 2 * ((size_t)1 << l1) + 2 * ((size_t)1 << l2);
+  return 2 * half + 2 * ((size_t)1 << l1) + 2 * ((size_t)1 << l2) + (ntt_table29_entries(log_m) * 36 + 31) / 32;
 }
 
 // Points D at `storage` (ntt_table_elems(log_m) elements) and, when `fill` is set, queues the kernels that compute the
@@ -79,6 +94,11 @@ int ntt_fill_tables(zg_ctx* ctx, unsigned log_m, Fr* storage, NttDomain<Fr>* D, 
   Fr* g_lo = p; p += N2;
   Fr* gi_lo = p; p += N1;
   Fr* gi_hi = p; p += N2;
+  uint32_t* twa29 = reinterpret_cast<uint32_t*>(p);
+  uint32_t* twai29 = twa29 + 9 * (size_t)(N1 > 1 ? N1 / 2 : 1);
+  uint32_t* twb29 = twa29 + 9 * (size_t)N1;
+  uint32_t* twbi29 = twb29 + 9 * (size_t)(N2 > 1 ? N2 / 2 : 1);
+  uint32_t* g_hi29 = twb29 + 9 * (size_t)N2;
   // w = root_of_unity^(2^(s - log m))  (libfqfft get_root_of_unity)
   Fr w = fr_from_limbs<Fr>(P::ROOT_MONT), wi = fr_from_limbs<Fr>(P::ROOT_INV_MONT);
   for (unsigned i = log_m; i < (unsigned)P::TWO_ADICITY; i++) {
@@ -99,6 +119,15 @@ int ntt_fill_tables(zg_ctx* ctx, unsigned log_m, Fr* storage, NttDomain<Fr>* D, 
     launch(g_lo, g, 1, Fr::one(), N2);
     launch(gi_lo, gi, 1, minv, N1);
     launch(gi_hi, gi, N1, Fr::one(), N2);
+    // dst[i] = src[i * stride] in the reduced-radix form
+    auto to29 = [&](const Fr* src, uint32_t stride, uint32_t* dst, uint32_t count) {
+      if (count) hipLaunchKernelGGL((k_to_radix29<Fr>), dim3((count + 255) / 256), dim3(256), 0, st, src, stride, dst, count);
+    };
+    to29(tw, N2, twa29, N1 / 2);  // (w^N2)^j: the N1-point transforms of pass A
+    to29(twi, N2, twai29, N1 / 2);
+    to29(tw, N1, twb29, N2 / 2);  // (w^N1)^j: the N2-point transforms of pass B
+    to29(twi, N1, twbi29, N2 / 2);
+    to29(g_hi, 1, g_hi29, N1);
     ZG_HIP(hipGetLastError());
   }
   D->T.log_m = log_m;
@@ -108,6 +137,11 @@ int ntt_fill_tables(zg_ctx* ctx, unsigned log_m, Fr* storage, NttDomain<Fr>* D, 
   D->T.g_lo = g_lo;
   D->T.gi_lo = gi_lo;
   D->T.gi_hi = gi_hi;
+  D->T.twa29 = twa29;
+  D->T.twa_inv29 = twai29;
+  D->T.twb29 = twb29;
+  D->T.twb_inv29 = twbi29;
+  D->T.g_hi29 = g_hi29;
   D->T.m_inv = minv;
   D->T.log_n1 = l1;
   D->T.log_n2 = l2;
@@ -155,7 +189,7 @@ int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, 
   static std::once_flag attr_once;  // clones of a key prove from several threads (zg_pk_clone)
   hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
-    const int lim = NTT_LDS_ELEMS * 32;
+    const int lim = NTT_LDS_SLOTS * 36;
     const void* kernels[] = {(const void*)k_ntt_pass_a<Fr, false, RMAX>, (const void*)k_ntt_pass_a<Fr, true, RMAX>,
                              (const void*)k_ntt_pass_b<Fr, 0, RMAX>, (const void*)k_ntt_pass_b<Fr, 1, RMAX>,
                              (const void*)k_ntt_pass_b<Fr, 2, RMAX>};
@@ -167,7 +201,8 @@ int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, 
   const uint32_t TC = D->TC, TR = D->TR;
   const unsigned log_tc = ilog2_u32(TC), log_tr = ilog2_u32(TR);
   hipStream_t st = ctx->stream;
-  const size_t lds_a = (size_t)N1 * TC * 32, lds_b = (size_t)N2 * TR * 32;
+  auto lds_bytes = [](uint32_t elems) { return (size_t)(elems + elems / 64 + 1) * 36; };
+  const size_t lds_a = lds_bytes(N1 * TC), lds_b = lds_bytes(N2 * TR);
   auto threads = [](uint32_t elems) {
     uint32_t t = elems >> RMAX;  // lds_fft: 2^RMAX elements per work item
     if (t < 64) t = 64;
