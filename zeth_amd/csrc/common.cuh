@@ -53,6 +53,10 @@ struct zg_ctx {
   int job_W = 0, job_c = 0;
   int job_table_gbits = -1;  // >= 0: the job ran in fixed-base table mode with 2^gbits bucket groups
   bool want_dense = false;  // count scalars other than 0/1 during recoding (prover lanes)
+  // Bucket segments per window of the reduction (power of two; 0: the plan's own choice).  A caller whose evaluation is
+  // not on its critical path (the prover's side lanes) asks for fewer: each segment's lane then pays the c-bit weighting
+  // once for more buckets -- less work for the device, a longer dependent chain for this evaluation.
+  uint32_t reduce_segments = 0;
   uint32_t job_dense = 0;  // scalars other than 0/1 seen by the last MSM on this context
   int pinned_reserve(size_t bytes) {
     if (bytes <= pinned_cap) return ZG_OK;

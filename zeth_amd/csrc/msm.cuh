@@ -27,6 +27,7 @@
 
 #include "accum29.cuh"
 #include "curve.cuh"
+#include "curve_quad.cuh"
 
 namespace zg {
 
@@ -36,6 +37,7 @@ static constexpr int MSM_MAX_C = 16;
 // table-mode top digit (11 units at 2^25 points, 22 at 2^26) took it 8 ms against 0.4-0.8 ms folded serially.
 static constexpr uint32_t COMBINE_SERIAL_MAX = 8, COMBINE_SERIAL_MAX_TABLE = 32;
 static constexpr uint32_t COMBINE_CHUNK = 512;     // units per workgroup and launch of the tree
+static constexpr uint32_t COMBINE_HEAVY_SLOTS = 32;  // heavy buckets the tree takes side by side (grid.y)
 // Units are handed to the accumulation kernel longest first, by length class: class UNIT_CLASSES = full-length units,
 // classes 0..1023 = partial units by (len - 1) * 1024 / L -- one class per length, since L <= 1024: the lanes of a wave
 // run in lockstep to the longest unit among them, and classes a few entries wide cost the accumulation ~10 % at 2^24
@@ -823,10 +825,21 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
 }
 
 // Buckets that were split into several units (skewed scalars: 0/1-heavy witnesses, short top windows) are folded into
-// their first unit.  Up to COMBINE_SERIAL_MAX units: the first unit's lane adds the others one after another
+// their first unit.  Up to COMBINE_SERIAL_MAX units: the first unit's QUAD adds the others one after another
 // (k_combine_light).  More ("heavy" buckets, listed by k_units -- a JoinSplit witness has one, holding half of all
-// entries in thousands of units): a tree with the active lanes compacted onto the first waves of a 256-lane workgroup,
-// 512 units per workgroup and launch (k_combine_tree with stride 1, then stride 512 over the chunk heads).
+// entries in thousands of units): a tree, 512 units per workgroup and launch (k_combine_tree with stride 1, then stride
+// 512 over the chunk heads).
+//
+// These kernels and the bucket reduction below are chains of dependent full additions with little parallel work: every
+// point is handled by the four lanes of a quad (curve_quad.cuh), one coordinate and one field product per lane and
+// round, which shortens each addition from 14 dependent products to 4.
+
+// threads of a workgroup of the quad kernels: wider fields hold more registers per lane
+template <class F>
+constexpr int quad_block() {
+  return sizeof(F) <= 32 ? 1024 : (sizeof(F) <= 64 ? 512 : 256);
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restrict__ units, const uint32_t* __restrict__ wunits,
                                                         uint32_t W, uint32_t cap, const uint32_t* __restrict__ cnt,
@@ -834,30 +847,28 @@ __global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restric
                                                         XYZZ<F>* __restrict__ part, uint32_t smax) {
   if (wunits[W] <= 1) return;  // no bucket has more than one unit
   const uint32_t w = blockIdx.y;
-  const uint32_t ul = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ul = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
   if (ul >= wunits[w]) return;
   const uint32_t u = w * cap + ul;
   const uint32_t b = units[u].bucket;
   if (ufirst[b] != u) return;  // only a bucket's first unit
   const uint32_t nu = (cnt[b] + L - 1) / L;
   if (nu < 2 || nu > smax) return;
-  XYZZ<F> a = part[u];
-  for (uint32_t k = 1; k < nu; k++) {
-    XYZZ<F> c = part[u + k];
-    xyzz_add(a, c);
-  }
-  part[u] = a;
+  F a = quad_load(part + u, q);
+  for (uint32_t k = 1; k < nu; k++) a = quad_add(a, quad_load(part + u + k, q), q);
+  quad_store(part + u, q, a);
 }
 
 // grid (chunk slots, heavy slots); elements of this level: part[first + stride * j], j < ceil(units / stride)
 template <class F>
-__global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
-                                                       const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
-                                                       uint32_t L, uint32_t stride, XYZZ<F>* __restrict__ part,
-                                                       const uint32_t* __restrict__ max_units /* most units in any bucket */) {
+__global__ void __launch_bounds__(quad_block<F>()) k_combine_tree(const uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
+                                                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
+                                                                   uint32_t L, uint32_t stride, XYZZ<F>* __restrict__ part,
+                                                                   const uint32_t* __restrict__ max_units /* most units in any bucket */) {
   // chunk slots beyond the longest bucket have nothing to do in any heavy bucket
   if ((size_t)blockIdx.x * COMBINE_CHUNK * stride >= max_units[0]) return;
   const uint32_t nheavy = heavy[0];
+  const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
   for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
     const uint32_t g = heavy[1 + hi];
     const uint32_t nu = (cnt[g] + L - 1) / L;
@@ -867,12 +878,10 @@ __global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict
     for (uint32_t c0 = blockIdx.x * COMBINE_CHUNK; c0 < nelem; c0 += gridDim.x * COMBINE_CHUNK) {
       const uint32_t c1 = c0 + COMBINE_CHUNK < nelem ? c0 + COMBINE_CHUNK : nelem;
       for (uint32_t s = 1; s < COMBINE_CHUNK && c0 + s < c1; s <<= 1) {
-        const uint32_t j0 = c0 + 2 * s * threadIdx.x;
-        if (j0 + s < c1) {
-          XYZZ<F> a = base[(size_t)stride * j0];
-          XYZZ<F> c = base[(size_t)stride * (j0 + s)];
-          xyzz_add_inl(a, c);
-          base[(size_t)stride * j0] = a;
+        for (uint32_t j0 = c0 + 2 * s * qi; j0 + s < c1; j0 += 2 * s * nq) {
+          const F a = quad_load(base + (size_t)stride * j0, q);
+          const F c = quad_load(base + (size_t)stride * (j0 + s), q);
+          quad_store(base + (size_t)stride * j0, q, quad_add(a, c, q));
         }
         __syncthreads();
       }
@@ -883,53 +892,47 @@ __global__ void __launch_bounds__(256) k_combine_tree(const uint32_t* __restrict
 // ---------------------------------------------------------------------------------------------
 // bucket reduction
 // ---------------------------------------------------------------------------------------------
-// lane (w, j): buckets [j*k, (j+1)*k) of window w; seg[w*T + j] = sum_b (b + 1) * B_b over the segment
+// quad (w, j): buckets [j*k, (j+1)*k) of window w; seg[w*T + j] = sum_b (b + 1) * B_b over the segment
 template <class F>
 __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
                                                   const XYZZ<F>* __restrict__ part, uint32_t nb, uint32_t T, uint32_t k,
                                                   uint32_t L, uint32_t W, XYZZ<F>* __restrict__ seg,
                                                   XYZZ<F>* __restrict__ seg_plain /* table mode: unweighted segment sums; else null */) {
-  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
   if (g >= T * W) return;
-  uint32_t w = g / T, j = g % T;
-  XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf();
+  const uint32_t w = g / T, j = g % T;
+  F run = F::zero(), tot = F::zero();  // the identity: every coordinate zero
   for (int bb = (int)k - 1; bb >= 0; bb--) {
-    size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
-    if (cnt[gid]) xyzz_add_inl(run, part[ufirst[gid]]);  // k_combine left the bucket sum in its first unit
-    xyzz_add_inl(tot, run);
+    const size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
+    if (cnt[gid]) run = quad_add(run, quad_load(part + ufirst[gid], q), q);  // k_combine left the bucket sum in its first unit
+    tot = quad_add(tot, run, q);
   }
-  // tot = sum (b - j*k + 1) B_b ; add (j*k) * run
-  uint32_t start = j * k;
-  if (start != 0 && !run.is_inf()) {
-    XYZZ<F> r = XYZZ<F>::inf();
-    for (int b = 15; b >= 0; b--) {
-      r = xyzz_dbl_inl(r);
-      if ((start >> b) & 1u) xyzz_add_inl(r, run);
-    }
-    xyzz_add_inl(tot, r);
+  // tot = sum (b - j*k + 1) B_b ; add (j*k) * run, j*k < nb
+  const uint32_t start = j * k;
+  F r = F::zero();
+  for (int b = 31 - __builtin_clz(nb > 1 ? nb - 1 : 1); b >= 0; b--) {
+    r = quad_dbl(r, q);
+    if ((start >> b) & 1u) r = quad_add(r, run, q);
   }
-  seg[g] = tot;
-  if (seg_plain) seg_plain[g] = run;
+  tot = quad_add(tot, r, q);
+  quad_store(seg + g, q, tot);
+  if (seg_plain) quad_store(seg_plain + g, q, run);
 }
 
-// one block of T lanes per window: tree-sum seg[w*T .. w*T+T) into seg[w*T]
+// one block per window: tree-sum seg[w*T .. w*T+T) into seg[w*T]
 template <class F>
-__global__ void __launch_bounds__(1024) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
+__global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
   XYZZ<F>* s = seg + (size_t)blockIdx.x * T;  // (table mode: the unweighted sums follow as gridDim.x / 2 more rows)
-  if (T > blockDim.x) {  // fold the tail onto the first blockDim entries
-    XYZZ<F> a = s[threadIdx.x];
-    for (uint32_t j = threadIdx.x + blockDim.x; j < T; j += blockDim.x) xyzz_add_inl(a, s[j]);
-    s[threadIdx.x] = a;
+  const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
+  if (T > nq) {  // fold the tail onto the first nq entries
+    F a = quad_load(s + qi, q);
+    for (uint32_t j = qi + nq; j < T; j += nq) a = quad_add(a, quad_load(s + j, q), q);
+    quad_store(s + qi, q, a);
     __syncthreads();
-    T = blockDim.x;
+    T = nq;
   }
   for (uint32_t h = T >> 1; h >= 1; h >>= 1) {
-    if (threadIdx.x < h) {
-      XYZZ<F> a = s[threadIdx.x];
-      XYZZ<F> b = s[threadIdx.x + h];
-      xyzz_add_inl(a, b);
-      s[threadIdx.x] = a;
-    }
+    if (qi < h) quad_store(s + qi, q, quad_add(quad_load(s + qi, q), quad_load(s + qi + h, q), q));
     __syncthreads();
   }
 }

@@ -179,7 +179,11 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     d_bases += tab->first;
     tab = nullptr;
   }
-  const MsmPlan plan = tab ? msm_make_table_plan(n, Fr::Params::BITS, tab->c, tab->D) : msm_make_plan(n, Fr::Params::BITS, force_c);
+  MsmPlan plan = tab ? msm_make_table_plan(n, Fr::Params::BITS, tab->c, tab->D) : msm_make_plan(n, Fr::Params::BITS, force_c);
+  if (ctx->reduce_segments && ctx->reduce_segments < plan.T) {  // fewer, longer bucket segments: less work, longer chain
+    plan.T = ctx->reduce_segments;
+    plan.k = plan.nb / plan.T;
+  }
   const MsmPlan& p = plan;
   ctx->job_W = p.W;
   ctx->job_c = p.c;
@@ -336,24 +340,31 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                        order, sorted, d_bases, part, zg_debug_base_mask(), w_lo, 0u);
   }
   ctx->mark("combine");
-  hipLaunchKernelGGL((k_combine_light<F>), dim3((p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
+  hipLaunchKernelGGL((k_combine_light<F>), dim3((4 * p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
                      p.cap, cnt, ufirst, p.L, part, p.smax);
   {
     uint32_t chunks = (p.cap + COMBINE_CHUNK - 1) / COMBINE_CHUNK;
     if (chunks > 64) chunks = 64;
-    // up to 1024 heavy buckets side by side (the 4096 values of a 12-bit top digit are heavy from 2^25 points on);
-    // workgroups beyond the heavy count or a bucket's chunk count leave at once
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, 1u, part, wunits + p.W);
-    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 1024), dim3(256), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part, wunits + p.W);
+    // COMBINE_HEAVY_SLOTS heavy buckets side by side, the rest in turn (the 4096 values of a 12-bit top digit are heavy
+    // from 2^25 points on); workgroups beyond the heavy count or a bucket's chunk count leave at once -- a JoinSplit
+    // witness has ONE heavy bucket, so the grid is kept small: a million waves launched to exit cost the proof's other
+    // streams their dispatch slots
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(chunks, COMBINE_HEAVY_SLOTS), dim3(quad_block<F>()), 0, st, heavy, cnt, ufirst, p.L, 1u, part, wunits + p.W);
+    hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, COMBINE_HEAVY_SLOTS), dim3(quad_block<F>()), 0, st, heavy, cnt, ufirst, p.L, COMBINE_CHUNK, part, wunits + p.W);
     if (WN / Wn / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK || (tab && WN / p.L >= (size_t)COMBINE_CHUNK * COMBINE_CHUNK))  // more than 2^18 units in one bucket: a third level
-      hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(256), 0, st, heavy, cnt, ufirst, p.L,
+      hipLaunchKernelGGL((k_combine_tree<F>), dim3(1, 16), dim3(quad_block<F>()), 0, st, heavy, cnt, ufirst, p.L,
                          COMBINE_CHUNK * COMBINE_CHUNK, part, wunits + p.W);
   }
   ctx->mark("reduce1");
-  hipLaunchKernelGGL((k_reduce1<F>), dim3((p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
+  hipLaunchKernelGGL((k_reduce1<F>), dim3((4 * p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
                      p.k, p.L, (uint32_t)p.W, seg, tab ? seg + (size_t)p.W * p.T : (XYZZ<F>*)nullptr);
   ctx->mark("reduce2");
-  hipLaunchKernelGGL((k_reduce2<F>), dim3(rows), dim3(p.T < 1024 ? p.T : 1024), 0, st, seg, p.T);
+  {
+    uint32_t t2 = 4 * p.T;  // a quad per entry, up to the block the field's registers allow; at least a wave
+    if (t2 > (uint32_t)quad_block<F>()) t2 = quad_block<F>();
+    if (t2 < 64) t2 = 64;
+    hipLaunchKernelGGL((k_reduce2<F>), dim3(rows), dim3(t2), 0, st, seg, p.T);
+  }
   ctx->mark("end");
   ZG_HIP(hipGetLastError());
   // gather the W window sums (strided by T) with one 2D copy into pinned host memory
