@@ -58,8 +58,9 @@ __device__ __forceinline__ F fsel(bool take_b, const F& a, const F& b) {
   const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
   const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
   uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+  const uint32_t m = take_b ? 0xFFFFFFFFu : 0u;  // through a mask (v_bfi_b32): v_cndmask_b32 is several times slower on gfx950
 #pragma unroll
-  for (int i = 0; i < NW; i++) d[i] = take_b ? pb[i] : pa[i];
+  for (int i = 0; i < NW; i++) d[i] = (pb[i] & m) | (pa[i] & ~m);
   return r;
 }
 
