@@ -109,6 +109,60 @@ def test_adapter_generate_proof_from_protoboard_as_first_call(curve, tmp_path):
     assert M.verify(C, vk2, primary, M.proof_from_bytes(C, p3))
 
 
+def vk_to_bytes(C, vk):
+    """groth16_snark::verification_key_write_bytes (groth16_snark.tcc:77-91): ABC_g1 as libsnark's accumulation_vector,
+    first element then the rest as a sparse vector with indices 0..n-1 (stream_utils.tcc:111-139)."""
+    u64 = lambda x: x.to_bytes(8, "little")  # noqa: E731
+    rest = vk.ABC_g1[1:]
+    out = M.g1_to_bytes(C, vk.alpha_g1) + M.g2_to_bytes(C, vk.beta_g2) + M.g2_to_bytes(C, vk.delta_g2) + M.g1_to_bytes(C, vk.ABC_g1[0])
+    out += u64(len(rest)) + u64(len(rest))
+    for i, P in enumerate(rest):
+        out += u64(i) + M.g1_to_bytes(C, P)
+    return out
+
+
+def vk_from_bytes(C, raw):
+    n1, n2 = 2 * C.fq_bytes, 4 * C.fq_bytes
+    vk = M.VerificationKey()
+    vk.alpha_g1 = M.g1_from_bytes(C, raw[:n1])
+    vk.beta_g2 = M.g2_from_bytes(C, raw[n1:n1 + n2])
+    vk.delta_g2 = M.g2_from_bytes(C, raw[n1 + n2:n1 + 2 * n2])
+    pos = n1 + 2 * n2
+    vk.ABC_g1 = [M.g1_from_bytes(C, raw[pos:pos + n1])]
+    count = int.from_bytes(raw[pos + n1 + 8:pos + n1 + 16], "little")
+    pos += n1 + 16
+    for i in range(count):
+        assert int.from_bytes(raw[pos:pos + 8], "little") == i
+        vk.ABC_g1.append(M.g1_from_bytes(C, raw[pos + 8:pos + 8 + n1]))
+        pos += 8 + n1
+    assert pos == len(raw)
+    return vk
+
+
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_adapter_generator_from_secrets_and_generate_setup(curve, tmp_path):
+    """r1cs_gg_ppzksnark_generator_from_secrets in C++ (QAP evaluation at t on the host, batch_exp on the device) equals
+    the oracle's key byte for byte in the reference's on-disk formats -- the comparison mpc_test.cpp:344-365 makes
+    between the ceremony's key and the generator's; generate_setup (groth16_snark.tcc:18-25) with fresh secrets gives a
+    key whose proof verifies under its own verification key."""
+    C = CURVES[curve]
+    cs = M.simple_circuit(C, 4)
+    primary, aux = M.simple_circuit_assignment(C, [10, 12, 14, 16])
+    t, alpha, beta, delta = 0x1234567ABCDEF, 0x2345678, 0x3456789, 0x456789A0F
+    pk, vk = M.generator_from_secrets(C, cs, t, alpha, beta, delta)
+    (tmp_path / "r1cs").write_bytes(M.r1cs_to_bytes(C, cs))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    run(DRIVER, "setup", curve, tmp_path / "r1cs", "%x" % t, "%x" % alpha, "%x" % beta, "%x" % delta, tmp_path / "pk", tmp_path / "vk",
+        tmp_path / "proof", tmp_path / "asg", len(primary))
+    assert (tmp_path / "pk").read_bytes() == M.proving_key_to_bytes(C, pk)
+    assert (tmp_path / "vk").read_bytes() == vk_to_bytes(C, vk)
+    fresh_vk = vk_from_bytes(C, (tmp_path / "vk.fresh").read_bytes())
+    assert fresh_vk.alpha_g1 != vk.alpha_g1
+    proof = M.proof_from_bytes(C, (tmp_path / "proof").read_bytes())
+    assert M.verify(C, fresh_vk, primary, proof)
+    assert not M.verify(C, vk, primary, proof)
+
+
 @pytest.mark.parametrize("curve,group", [("alt-bn128", "g1"), ("alt-bn128", "g2"), ("bls12-377", "g1"), ("bls12-377", "g2")])
 def test_adapter_multi_exp(curve, group, tmp_path):
     """libzeth::multi_exp<ppT, GroupT>(gs, fs) (multi_exp.tcc:25-35): more bases than scalars is allowed and uses the

@@ -10,12 +10,16 @@
 //   prove CURVE pk assignment primary_inputs r_hex s_hex proof_fixed proof_random_1 proof_random_2
 //   multi_exp_sharded CURVE g1|g2 points scalars out_point n_shards     sharded_bases over n_shards contexts on device 0
 //   prove_pool CURVE pk assignment primary_inputs r_hex s_hex proof_a proof_b     device_proving_key_pool over {0, 0}
+//   setup CURVE r1cs t_hex alpha_hex beta_hex delta_hex pk_out vk_out proof_out assignment primary_inputs
+//          r1cs_gg_ppzksnark_generator_from_secrets (gpu_groth16_generator.hpp) written as pk_out / vk_out; then
+//          generate_setup with fresh secrets: vk_out.fresh and a proof made with that key in proof_out
 //   prove_pb CURVE pk assignment primary_inputs pk2 proof_1 proof_2 proof_3
 //          the FIRST library call is generate_proof(pk, pb) (groth16_snark.hpp:32-35); then the host key is overwritten in
 //          place with pk2 (same address, same sizes) and proved again: the stale device copy must not be used; then the
 //          device keys are released and the key proved once more; the process must exit cleanly
 #include <iostream>
 
+#include "../../include/libzeth_gpu/gpu_groth16_generator.hpp"
 #include "../../include/libzeth_gpu/gpu_groth16_snark.hpp"
 
 using namespace libzeth_gpu;
@@ -312,6 +316,46 @@ template<typename ppT> int cmd_prove_pb(char **argv)
 }
 
 // groth16_snark_test.cpp:39-171 (generate_test_data): the hand-made constraint system, proving key and assignment
+// setup <curve> <r1cs> <t> <alpha> <beta> <delta> <pk out> <vk out> <proof out> <assignment> <num inputs>:
+// the key from explicit secrets (mpc_test.cpp:344-365 compares the ceremony's key with this function's), written in the
+// reference's on-disk formats, and a proof made with that key from a randomly drawn setup as well
+template<typename ppT> int cmd_setup(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    r1cs_constraint_system<Fr<ppT>> cs;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        r1cs_read_bytes(cs, in_s);
+    }
+    const r1cs_gg_ppzksnark_keypair<ppT> kp =
+        r1cs_gg_ppzksnark_generator_from_secrets<ppT>(cs, from_hex<4>(argv[4]), from_hex<4>(argv[5]), from_hex<4>(argv[6]), from_hex<4>(argv[7]));
+    {
+        std::ofstream out_s = open_binary_output_file(argv[8]);
+        snarkT::proving_key_write_bytes(kp.pk, out_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[9]);
+        verification_key_write_bytes<ppT>(kp.vk, out_s);
+    }
+    // generate_setup: fresh secrets; the key must prove (checked by the caller with the verification key written here)
+    const r1cs_gg_ppzksnark_keypair<ppT> fresh = generate_setup<ppT>(cs);
+    r1cs_primary_input<Fr<ppT>> primary;
+    r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[11]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[12]), in_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[10]);
+        snarkT::proof_write_bytes(snarkT::generate_proof(fresh.pk, primary, auxiliary), out_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(std::string(argv[9]) + ".fresh");
+        verification_key_write_bytes<ppT>(fresh.vk, out_s);
+    }
+    return 0;
+}
+
 template<typename ppT> int cmd_testdata(char **argv)
 {
     using Field = Fr<ppT>;
@@ -425,6 +469,9 @@ template<typename ppT> int run(int argc, char **argv)
     }
     if (cmd == "prove" && argc >= 11) {
         return cmd_prove<ppT>(argv);
+    }
+    if (cmd == "setup" && argc >= 13) {
+        return cmd_setup<ppT>(argv);
     }
     if (cmd == "prove_pb" && argc >= 10) {
         return cmd_prove_pb<ppT>(argv);
