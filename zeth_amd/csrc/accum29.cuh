@@ -129,7 +129,8 @@ ZG_HD Acc29<P> madd29_fast(const Acc29<P>& a, const Affine<Fp<P>>& p, bool negat
   const auto PPP = f29::mul(Pd, PP);
   const auto Q = f29::mul(a.x, PP);
   const auto X3 = f29::carry(f29::sub(f29::sqr(R), f29::add(PPP, f29::dbl(Q))));
-  const auto Y3 = f29::sub(f29::mul(R, f29::sub(Q, X3)), f29::mul(a.y, PPP));
+  // Y3 = R (Q - X3) - Y1 PPP as R (Q - X3) + (k p - Y1) PPP: two products, one reduction
+  const auto Y3 = f29::mul_add(R, f29::sub(Q, X3), f29::carry(f29::neg(a.y)), PPP);
   A r;
   r.x = f29::widen<A::X::vb, A::X::lmax>(X3);
   r.y = f29::widen<A::Y::vb, A::Y::lmax>(Y3);

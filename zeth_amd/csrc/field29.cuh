@@ -100,6 +100,16 @@ struct K29 {
            ((unsigned __int128)1 << 64);
   }
 
+  // the same for the sum of two products sharing their columns (mul_add)
+  static constexpr bool column_fits2(uint64_t va, uint64_t la, uint64_t vb, uint64_t lb, uint64_t vc, uint64_t lc, uint64_t vd,
+                                     uint64_t ld) {
+    const uint64_t t = top_of_p() + 1;
+    const unsigned __int128 ea = la > va * t ? la : va * t, eb = lb > vb * t ? lb : vb * t;
+    const unsigned __int128 ec = lc > vc * t ? lc : vc * t, ed = ld > vd * t ? ld : vd * t;
+    return (unsigned __int128)NL * (ea * eb + ec * ed) + (unsigned __int128)NL * LNORM * LNORM + ((unsigned __int128)1 << (64 - B)) <
+           ((unsigned __int128)1 << 64);
+  }
+
   // k p in the redundant form used by sub(): every limb below the top raised by c 2^B - c (limb 0 by c 2^B) against c
   // borrowed from the limb above, so that z_i >= c (2^B - 1) + (digit i of k p) for i < NL - 1
   static constexpr Limbs sub_const(uint64_t k, uint64_t c) {
@@ -261,6 +271,45 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul(const E29<P, VA, LA>& a, const E29<P, VB, LB>
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
       if (j >= 0 && j < NL) mac(acc, a.v[i], b.v[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < NL) mac_const(acc, m[i], K::PL.v[j]);
+    }
+    if (k < NL) {
+      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
+      mac_const(acc, m[k], K::PL.v[0]);
+    } else {
+      r.v[k - NL] = (uint32_t)acc & K::MASK;
+    }
+    acc >>= B;
+  }
+  r.v[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// a b + c d in ONE Montgomery reduction: the columns of both products share their accumulators, so the second product
+// costs its NL^2 limb products but no second round of m_i p_j (a third of a product's multiplies).  Result < 2 p.
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB, uint64_t VC, uint64_t LC, uint64_t VD, uint64_t LD>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul_add(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b, const E29<P, VC, LC>& c,
+                                       const E29<P, VD, LD>& d) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  static_assert(K::column_fits2(VA, LA, VB, LB, VC, LC, VD, LD), "mul_add: a column overflows 64 bits -- carry() an operand first");
+  static_assert(VA * VB + VC * VD <= K::mont_room(), "mul_add: operands too large for a result below 2 p");
+  uint32_t m[NL];
+  E29<P, 2, K::LNORM> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) {
+        mac(acc, a.v[i], b.v[j]);
+        mac(acc, c.v[i], d.v[j]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NL; i++) {
