@@ -119,6 +119,13 @@ int zg_msm_ex(zg_bases* bases, size_t first, const void* scalars, size_t n, int 
 int zg_msm_sharded(zg_bases* const* shards, size_t n_shards, const void* const* scalars, const size_t* counts,
                    int scalar_form, int scalars_mem, int out_form, void* out_affine);
 
+/* Self-test of the reduced-radix field arithmetic the accumulation and transform kernels use (field29.cuh), run on
+ * the HOST build of the same templates against the 32-bit-limb arithmetic; needs no device.  field: 0 alt_bn128 Fq
+ * (+ the mixed addition on G1), 1 BLS12-377 Fq (+ G1), 2 alt_bn128 Fr, 3 BLS12-377 Fr.  No counterpart in the
+ * reference (its field arithmetic is libff's, tested there); it exists so that the CPU-only test tier covers the
+ * arithmetic the GPU kernels run. */
+int zg_selftest_reduced_radix(int field, int iters, uint64_t seed, int* mismatches);
+
 /* Which ROCm runtime serves this process, as a JSON object in buf: the libamdhip64 this library is bound to, its version,
  * and every libamdhip64 / libhsa-runtime64 image mapped into the process.  *mixed = 1 when more than one copy of either
  * is loaded or HIP and HSA come from different installations (a host that imports another ROCm copy, e.g. a Python

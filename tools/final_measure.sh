@@ -18,10 +18,14 @@ if [ "$1" = "1" ]; then
     timeout -k 10 300 python bench.py > "$O/bench.json" 2> "$O/bench.err" &&
     cat "$O/bench.json" &&
     cd /tmp &&
-    timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$O/prof_bench" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-prove > "$O/prof_bench.log" 2>&1 &&
-    timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/pmc_fetch" -o fetch -- python3 "$R/bench.py" --no-cpu-baseline --no-prove --steps 3 --warmup 1 > "$O/pmc_fetch.log" 2>&1 &&
-    timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O/pmc_write" -o write -- python3 "$R/bench.py" --no-cpu-baseline --no-prove --steps 3 --warmup 1 > "$O/pmc_write.log" 2>&1 &&
+    timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$O/prof_bench" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-prove --no-windowed --no-g2 --no-ntt > "$O/prof_bench.log" 2>&1 &&
+    timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/pmc_fetch" -o fetch -- python3 "$R/bench.py" --no-cpu-baseline --no-prove --no-windowed --no-g2 --no-ntt --steps 3 --warmup 1 > "$O/pmc_fetch.log" 2>&1 &&
+    timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O/pmc_write" -o write -- python3 "$R/bench.py" --no-cpu-baseline --no-prove --no-windowed --no-g2 --no-ntt --steps 3 --warmup 1 > "$O/pmc_write.log" 2>&1 &&
     timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/pmc_calib" -o calib -- "$R/build/calib_gather" > "$O/pmc_calib.log" 2>&1 &&
+    for lg in 19 22; do
+        timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_ntt${lg}_fetch" -- python3 "$R/tools/bench_sweep.py" ntt1 $lg 3 > "$O/pmc_ntt${lg}_fetch.log" 2>&1 &&
+        timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_ntt${lg}_write" -- python3 "$R/tools/bench_sweep.py" ntt1 $lg 3 > "$O/pmc_ntt${lg}_write.log" 2>&1 || exit 1
+    done &&
     echo part1 done
 elif [ "$1" = "2" ]; then
     timeout -k 10 200 python tools/bench_sweep.py g1 > "$O/msm_g1_sweep.jsonl" 2> "$O/sweep.err" &&
@@ -34,6 +38,9 @@ elif [ "$1" = "2" ]; then
     cat "$O/prove_joinsplit_shaped.json" &&
     cd /tmp &&
     timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$O/prof_prove" -o prove -- python3 "$R/tools/bench_prove.py" --no-cpu --in-flight 0 > "$O/prof_prove.log" 2>&1 &&
+    timeout -s KILL 200 rocprofv3 --kernel-trace -d "$O/prof_prove_if4" -o if4 -- python3 "$R/tools/bench_prove.py" --no-cpu --no-verify --in-flight 4 --steps 20 > "$O/prof_prove_if4.log" 2>&1 &&
+    timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/pmc_prove" -- python3 "$R/tools/bench_prove.py" --no-cpu --no-verify --in-flight 0 --steps 2 --warmup 1 > "$O/pmc_prove.log" 2>&1 &&
+    cd "$R" && timeout -k 10 600 python tools/bench_prove.py --curve bls12-377 --constraints 4194302 --steps 3 --warmup 1 --in-flight 0 --no-verify > "$O/prove_bls377_2p22.json" 2> "$O/prove_bls377.err" &&
     echo part2 done
 else
     echo "usage: $0 1|2" >&2

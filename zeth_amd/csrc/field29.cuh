@@ -22,7 +22,7 @@
 // writes 32-bit limbs.
 //
 // Replaces (inside k_accum and the transforms' butterflies) the same libff Fp_model arithmetic field.cuh restates; results are the same field
-// elements, so every MSM output stays bit-identical (tests/test_gpu_msm*.py, tests/test_field29.py).
+// elements, so every MSM output stays bit-identical (tests/test_gpu_msm*.py; host build checked by tests/test_field29.py through zg_selftest_reduced_radix).
 #pragma once
 #include <stdint.h>
 
