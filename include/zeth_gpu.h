@@ -121,7 +121,8 @@ int zg_msm_sharded(zg_bases* const* shards, size_t n_shards, const void* const* 
 
 /* Self-test of the reduced-radix field arithmetic the accumulation and transform kernels use (field29.cuh), run on
  * the HOST build of the same templates against the 32-bit-limb arithmetic; needs no device.  field: 0 alt_bn128 Fq
- * (+ the mixed addition on G1), 1 BLS12-377 Fq (+ G1), 2 alt_bn128 Fr, 3 BLS12-377 Fr.  No counterpart in the
+ * (+ the mixed addition on G1), 1 BLS12-377 Fq (+ G1), 2 alt_bn128 Fr, 3 BLS12-377 Fr, 4 / 5 the Fq2 product, square
+ * and G2 mixed addition of alt_bn128 / BLS12-377.  No counterpart in the
  * reference (its field arithmetic is libff's, tested there); it exists so that the CPU-only test tier covers the
  * arithmetic the GPU kernels run. */
 int zg_selftest_reduced_radix(int field, int iters, uint64_t seed, int* mismatches);

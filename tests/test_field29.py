@@ -9,7 +9,8 @@ import pytest
 
 import zeth_amd.lib as zl
 
-FIELDS = {0: "alt_bn128 Fq + G1 mixed addition", 1: "BLS12-377 Fq + G1 mixed addition", 2: "alt_bn128 Fr", 3: "BLS12-377 Fr"}
+FIELDS = {0: "alt_bn128 Fq + G1 mixed addition", 1: "BLS12-377 Fq + G1 mixed addition", 2: "alt_bn128 Fr", 3: "BLS12-377 Fr",
+          4: "alt_bn128 Fq2 + G2 mixed addition", 5: "BLS12-377 Fq2 + G2 mixed addition"}
 
 
 @pytest.mark.parametrize("field", sorted(FIELDS))

@@ -100,6 +100,16 @@ struct K29 {
            ((unsigned __int128)1 << 64);
   }
 
+  // the general form: a column of the sum of several products; each product contributes NL col_term()s
+  static constexpr unsigned __int128 col_term(uint64_t va, uint64_t la, uint64_t vb, uint64_t lb) {
+    const uint64_t t = top_of_p() + 1;
+    const unsigned __int128 ea = la > va * t ? la : va * t, eb = lb > vb * t ? lb : vb * t;
+    return ea * eb;
+  }
+  static constexpr bool columns_fit(unsigned __int128 terms) {
+    return (unsigned __int128)NL * terms + (unsigned __int128)NL * LNORM * LNORM + ((unsigned __int128)1 << (64 - B)) <
+           ((unsigned __int128)1 << 64);
+  }
   // the same for the sum of two products sharing their columns (mul_add)
   static constexpr bool column_fits2(uint64_t va, uint64_t la, uint64_t vb, uint64_t lb, uint64_t vc, uint64_t lc, uint64_t vd,
                                      uint64_t ld) {
@@ -326,6 +336,114 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul_add(const E29<P, VA, LA>& a, const E29<P, VB,
   }
   r.v[NL - 1] = (uint32_t)acc;
   return r;
+}
+
+// The column loop of the Montgomery product with the limb products supplied by the caller: macs(chain, i, j) adds every
+// term of weight 2^(B (i + j)) -- one limb product per operand pair -- to the column.  This is the form of the G2
+// accumulator (accum29x2.cuh), whose registers leave room for ONE wave per SIMD: there a single dependent chain of
+// v_mad_u64_u32 (and the wait states the assembler's hazard rules put around the instruction form of mac()) issues at a
+// third of the multiplier's rate, so the products here are plain C, every operand pair has a chain of its own, joined
+// once per column, and the compiler interleaves them (alt_bn128 G2, 2^22 points: k_accum 16.1 ms with the instruction
+// form, 11.8 ms this way; the 32-bit-limb path 15.7 ms).
+ZG_HD void mac_c(uint64_t& acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
+#ifndef ZG_F29_CHAINS
+#define ZG_F29_CHAINS 1
+#endif
+template <class P, int NPAIRS, class MacFn>
+ZG_HD E29<P, 2, K29<P>::LNORM> mont_columns(MacFn macs) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  constexpr int NC = ZG_F29_CHAINS ? NPAIRS : 1;
+  uint32_t m[NL];
+  E29<P, 2, K::LNORM> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+    uint64_t chain[NC];
+    chain[0] = acc;
+#pragma unroll
+    for (int c = 1; c < NC; c++) chain[c] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) macs(chain, i, j);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < NL) mac_c(chain[NC - 1], m[i], K::PL.v[j]);
+    }
+    acc = chain[0];
+#pragma unroll
+    for (int c = 1; c < NC; c++) acc += chain[c];
+    if (k < NL) {
+      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
+      mac_c(acc, m[k], K::PL.v[0]);
+    } else {
+      r.v[k - NL] = (uint32_t)acc & K::MASK;
+    }
+    acc >>= B;
+  }
+  r.v[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// a b in the same form (the Fq2 square's single products)
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul_chains(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
+  using K = K29<P>;
+  static_assert(K::column_fits(VA, LA, VB, LB), "mul: a column overflows 64 bits -- carry() an operand first");
+  static_assert(VA * VB <= K::mont_room(), "mul: operands too large for a result below 2 p");
+  return mont_columns<P, 1>([&](uint64_t* chain, int i, int j) { mac_c(chain[0], a.v[i], b.v[j]); });
+}
+
+// a b + c d with a chain per product (mul_add above keeps one: best with two or more waves on a SIMD)
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB, uint64_t VC, uint64_t LC, uint64_t VD, uint64_t LD>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul_add_chains(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b, const E29<P, VC, LC>& c,
+                                              const E29<P, VD, LD>& d) {
+  using K = K29<P>;
+  static_assert(K::column_fits2(VA, LA, VB, LB, VC, LC, VD, LD), "mul_add: a column overflows 64 bits -- carry() an operand first");
+  static_assert(VA * VB + VC * VD <= K::mont_room(), "mul_add: operands too large for a result below 2 p");
+  return mont_columns<P, 2>([&](uint64_t* chain, int i, int j) {
+    constexpr int S = ZG_F29_CHAINS ? 1 : 0;
+    mac_c(chain[0], a.v[i], b.v[j]);
+    mac_c(chain[1 * S], c.v[i], d.v[j]);
+  });
+}
+
+// a1 b1 + a2 b2 + a3 b3 and a1 b1 + ... + a4 b4 in one reduction (the Fq2 formulas of accum29x2.cuh)
+template <class P, uint64_t V1, uint64_t L1, uint64_t W1, uint64_t M1, uint64_t V2, uint64_t L2, uint64_t W2, uint64_t M2, uint64_t V3,
+          uint64_t L3, uint64_t W3, uint64_t M3>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul_add3(const E29<P, V1, L1>& a1, const E29<P, W1, M1>& b1, const E29<P, V2, L2>& a2,
+                                        const E29<P, W2, M2>& b2, const E29<P, V3, L3>& a3, const E29<P, W3, M3>& b3) {
+  using K = K29<P>;
+  static_assert(K::columns_fit(K::col_term(V1, L1, W1, M1) + K::col_term(V2, L2, W2, M2) + K::col_term(V3, L3, W3, M3)),
+                "mul_add3: a column overflows 64 bits -- carry() an operand first");
+  static_assert(V1 * W1 + V2 * W2 + V3 * W3 <= K::mont_room(), "mul_add3: operands too large for a result below 2 p");
+  return mont_columns<P, 3>([&](uint64_t* chain, int i, int j) {
+    constexpr int S = ZG_F29_CHAINS ? 1 : 0;
+    mac_c(chain[0], a1.v[i], b1.v[j]);
+    mac_c(chain[1 * S], a2.v[i], b2.v[j]);
+    mac_c(chain[2 * S], a3.v[i], b3.v[j]);
+  });
+}
+template <class P, uint64_t V1, uint64_t L1, uint64_t W1, uint64_t M1, uint64_t V2, uint64_t L2, uint64_t W2, uint64_t M2, uint64_t V3,
+          uint64_t L3, uint64_t W3, uint64_t M3, uint64_t V4, uint64_t L4, uint64_t W4, uint64_t M4>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul_add4(const E29<P, V1, L1>& a1, const E29<P, W1, M1>& b1, const E29<P, V2, L2>& a2,
+                                        const E29<P, W2, M2>& b2, const E29<P, V3, L3>& a3, const E29<P, W3, M3>& b3,
+                                        const E29<P, V4, L4>& a4, const E29<P, W4, M4>& b4) {
+  using K = K29<P>;
+  static_assert(K::columns_fit(K::col_term(V1, L1, W1, M1) + K::col_term(V2, L2, W2, M2) + K::col_term(V3, L3, W3, M3) +
+                               K::col_term(V4, L4, W4, M4)),
+                "mul_add4: a column overflows 64 bits -- carry() an operand first");
+  static_assert(V1 * W1 + V2 * W2 + V3 * W3 + V4 * W4 <= K::mont_room(), "mul_add4: operands too large for a result below 2 p");
+  return mont_columns<P, 4>([&](uint64_t* chain, int i, int j) {
+    constexpr int S = ZG_F29_CHAINS ? 1 : 0;
+    mac_c(chain[0], a1.v[i], b1.v[j]);
+    mac_c(chain[1 * S], a2.v[i], b2.v[j]);
+    mac_c(chain[2 * S], a3.v[i], b3.v[j]);
+    mac_c(chain[3 * S], a4.v[i], b4.v[j]);
+  });
 }
 
 // a^2: the cross products once, against the doubled operand

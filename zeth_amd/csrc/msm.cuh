@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "accum29.cuh"
+#include "accum29x2.cuh"
 #include "curve.cuh"
 #include "curve_quad.cuh"
 
@@ -735,9 +736,12 @@ __device__ __forceinline__ void xyzz_madd_wave(XYZZ<F>& acc, const Affine<F>& p)
   acc.zzz = F::mul(acc.zzz, PPP);
 }
 
-// which coordinate fields accumulate in the reduced-radix form (G1 of both curves; G2 keeps the 32-bit-limb path)
+// which coordinate fields accumulate in the reduced-radix form: Fq (G1, accum29.cuh) and Fq2 (G2, accum29x2.cuh)
 #ifndef ZG_ACCUM_RADIX29
 #define ZG_ACCUM_RADIX29 1
+#endif
+#ifndef ZG_ACCUM_RADIX29_G2
+#define ZG_ACCUM_RADIX29_G2 1
 #endif
 template <class F>
 struct Radix29For {
@@ -746,6 +750,10 @@ struct Radix29For {
 template <class P>
 struct Radix29For<Fp<P>> {
   static constexpr bool value = ZG_ACCUM_RADIX29 != 0;
+};
+template <class P, int NR>
+struct Radix29For<Fp2<Fp<P>, NR>> {
+  static constexpr bool value = ZG_ACCUM_RADIX29_G2 != 0;
 };
 
 #ifndef ZG_ACCUM_TOUCH
@@ -784,9 +792,10 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
   uint32_t en = ent[last < 1 ? last : 1];
   Affine<F> p = load_affine(bases, e & idx_mask);
   if constexpr (Radix29For<F>::value) {
-    // G1: the accumulator lives in the reduced-radix form (accum29.cuh) and returns to the stored form once per unit
-    using P = typename F::Params;
-    Acc29<P> acc = acc29_from_affine<P>(p, (e >> 31) != 0);
+    // the accumulator lives in the reduced-radix form (accum29.cuh, accum29x2.cuh) and returns to the stored form once per
+    // unit
+    using A = AccumOf<F>;
+    typename A::Acc acc = A::from_affine(p, (e >> 31) != 0);
     p = load_affine(bases, en & idx_mask);
     e = en;
     en = ent[last < 2 ? last : 2];
@@ -803,7 +812,7 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
 #if ZG_ACCUM_PIN_LOADS
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      acc = madd29<P>(acc, p, (e >> 31) != 0);
+      acc = A::madd(acc, p, (e >> 31) != 0);
       e = en;
       en = en2;
       p = pn;
@@ -812,7 +821,7 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
       touch_prev = touch;
 #endif
     }
-    part[u] = acc29_to_xyzz<P>(acc);
+    part[u] = A::to_xyzz(acc);
   } else {
     p.y = F::cneg(p.y, (e >> 31) != 0);
     XYZZ<F> acc = XYZZ<F>::from_affine(p);

@@ -5,6 +5,7 @@
 
 #include "../../include/zeth_gpu.h"
 #include "accum29.cuh"
+#include "accum29x2.cuh"
 #include "curve_constants.h"
 #include "field29.cuh"
 
@@ -130,6 +131,78 @@ int check_mixed_addition() {
   return bad;
 }
 
+// the G2 mixed addition (accum29x2.cuh) against xyzz_madd over Fp2, and the Fq2 product and square
+template <class P, int NR, class GP>
+int check_mixed_addition_g2(int iters, uint64_t seed) {
+  using B = Fp<P>;
+  using F = Fp2<B, NR>;
+  using Q = F29x2<P, NR>;
+  using A = AccumOf<F>;
+  Rng g{seed | 1};
+  int bad = 0;
+  for (int t = 0; t < iters; t++) {
+    const F a{random_element<P>(g, t), random_element<P>(g, t + 7)}, b{random_element<P>(g, t + 50), random_element<P>(g, t + 3)};
+    const auto ra = Q::normalise(Q::unpack(a));
+    bad += !(Q::pack(Q::mul(ra, Q::unpack(b))) == F::mul(a, b));
+    bad += !(Q::pack(Q::sqr(ra)) == F::sqr(a));
+    bad += !(Q::pack(Q::sqr(f29::carry(f29::sub(ra, Q::normalise(Q::unpack(b)))))) == F::sqr(F::sub(a, b)));
+  }
+  Affine<F> gen;
+  for (int k = 0; k < B::N; k++) {
+    gen.x.c0.v[k] = GP::GX_C0_MONT[k];
+    gen.x.c1.v[k] = GP::GX_C1_MONT[k];
+    gen.y.c0.v[k] = GP::GY_C0_MONT[k];
+    gen.y.c1.v[k] = GP::GY_C1_MONT[k];
+  }
+  Affine<F> pts[6];
+  XYZZ<F> t = XYZZ<F>::from_affine(gen);
+  for (int i = 0; i < 6; i++) {
+    pts[i] = xyzz_to_affine(t);
+    t = xyzz_dbl(t);
+    xyzz_madd(t, gen);
+  }
+  auto same = [](const typename A::Acc& a, const XYZZ<F>& r) {
+    const XYZZ<F> x = A::to_xyzz(a);
+    if (x.is_inf() || r.is_inf()) return x.is_inf() == r.is_inf();
+    const Affine<F> p = xyzz_to_affine(x), q = xyzz_to_affine(r);
+    return p.x == q.x && p.y == q.y;
+  };
+  const int seq[] = {-1, 0, 0, 1, 2, -1, 3, 4, 5, 0, 1};
+  const int neg[] = {0, 0, 0, 0, 1, 0, 0, 1, 0, 1, 1};
+  XYZZ<F> ref = XYZZ<F>::inf();
+  typename A::Acc acc = A::from_affine(Affine<F>::inf(), false);
+  for (int s = 0; s < 11; s++) {
+    const Affine<F> p = seq[s] < 0 ? Affine<F>::inf() : pts[seq[s]];
+    Affine<F> ps = p;
+    ps.y = F::cneg(p.y, neg[s] != 0);
+    xyzz_madd(ref, ps);
+    acc = A::madd(acc, p, neg[s] != 0);
+    bad += !same(acc, ref);
+  }
+  for (int rep = 0; rep < 2; rep++) {  // P + P and P - P, then on
+    XYZZ<F> r2 = XYZZ<F>::from_affine(pts[2]);
+    typename A::Acc a2 = A::from_affine(pts[2], false);
+    Affine<F> q = pts[2];
+    q.y = F::cneg(q.y, rep != 0);
+    xyzz_madd(r2, q);
+    a2 = A::madd(a2, pts[2], rep != 0);
+    bad += !same(a2, r2);
+    xyzz_madd(r2, pts[4]);
+    a2 = A::madd(a2, pts[4], false);
+    bad += !same(a2, r2);
+  }
+  for (int i = 0; i < 200; i++) {
+    const Affine<F> p = pts[(i * 7 + 3) % 6];
+    const bool n = (i % 3) == 1;
+    Affine<F> ps = p;
+    ps.y = F::cneg(p.y, n);
+    xyzz_madd(ref, ps);
+    acc = A::madd(acc, p, n);
+  }
+  bad += !same(acc, ref);
+  return bad;
+}
+
 }  // namespace
 
 extern "C" int zg_selftest_reduced_radix(int field, int iters, uint64_t seed, int* mismatches) {
@@ -139,6 +212,8 @@ extern "C" int zg_selftest_reduced_radix(int field, int iters, uint64_t seed, in
     case 1: *mismatches = check_field<Bls377FqParams>(iters, seed) + check_mixed_addition<Bls377FqParams, Bls377G1Params>(); break;
     case 2: *mismatches = check_field<Bn254FrParams>(iters, seed); break;
     case 3: *mismatches = check_field<Bls377FrParams>(iters, seed); break;
+    case 4: *mismatches = check_mixed_addition_g2<Bn254FqParams, 1, Bn254G2Params>(iters, seed); break;
+    case 5: *mismatches = check_mixed_addition_g2<Bls377FqParams, 5, Bls377G2Params>(iters, seed); break;
     default: return ZG_ERR_INVALID_ARGUMENT;
   }
   return ZG_OK;
