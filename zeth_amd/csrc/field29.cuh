@@ -185,6 +185,79 @@ ZG_HD void mac_const(uint64_t& acc, uint32_t a, uint32_t k) {
 #endif
 }
 
+// Several products of one column in ONE statement.  The compiler puts a wait state (s_nop) behind every inline-asm
+// statement whose result the next instruction reads (gfx940's dst_sel forwarding rule, applied to asm it cannot look
+// into); v_mad_u64_u32 has no dst_sel, so a column's chain written as one statement needs none of them.
+#ifndef ZG_F29_ASM_BLOCKS
+#define ZG_F29_ASM_BLOCKS 1
+#endif
+ZG_HD void mac2(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM && ZG_F29_ASM_BLOCKS
+  uint64_t co;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=s"(co) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+#else
+  mac(acc, a0, b0);
+  mac(acc, a1, b1);
+#endif
+}
+ZG_HD void mac4(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM && ZG_F29_ASM_BLOCKS
+  uint64_t co;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+      : "+v"(acc), "=s"(co)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+#else
+  mac2(acc, a0, b0, a1, b1);
+  mac2(acc, a2, b2, a3, b3);
+#endif
+}
+ZG_HD void mac2_const(uint64_t& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM && ZG_F29_ASM_BLOCKS
+  uint64_t co;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=s"(co) : "v"(a0), "s"(k0), "v"(a1), "s"(k1));
+#else
+  mac_const(acc, a0, k0);
+  mac_const(acc, a1, k1);
+#endif
+}
+ZG_HD void mac4_const(uint64_t& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1, uint32_t a2, uint32_t k2, uint32_t a3, uint32_t k3) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM && ZG_F29_ASM_BLOCKS
+  uint64_t co;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+      : "+v"(acc), "=s"(co)
+      : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3));
+#else
+  mac2_const(acc, a0, k0, a1, k1);
+  mac2_const(acc, a2, k2, a3, k3);
+#endif
+}
+
+// acc += sum over i in [lo, hi] of x[i] * y[k - i]  (one column's share of a product), in blocks of four
+template <int NLIMBS>
+ZG_HD void mac_column(uint64_t& acc, const uint32_t (&x)[NLIMBS], const uint32_t (&y)[NLIMBS], int k, int lo, int hi) {
+#pragma unroll
+  for (int i = 0; i < NLIMBS; i += 4) {
+    const int i0 = lo + i;
+    const int n = hi - i0 + 1;
+    if (n >= 4) mac4(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1], x[i0 + 2], y[k - i0 - 2], x[i0 + 3], y[k - i0 - 3]);
+    else if (n == 3) { mac2(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]); mac(acc, x[i0 + 2], y[k - i0 - 2]); }
+    else if (n == 2) mac2(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]);
+    else if (n == 1) mac(acc, x[i0], y[k - i0]);
+  }
+}
+template <int NLIMBS>
+ZG_HD void mac_column_const(uint64_t& acc, const uint32_t (&x)[NLIMBS], const uint32_t (&y)[NLIMBS], int k, int lo, int hi) {
+#pragma unroll
+  for (int i = 0; i < NLIMBS; i += 4) {
+    const int i0 = lo + i;
+    const int n = hi - i0 + 1;
+    if (n >= 4) mac4_const(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1], x[i0 + 2], y[k - i0 - 2], x[i0 + 3], y[k - i0 - 3]);
+    else if (n == 3) { mac2_const(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]); mac_const(acc, x[i0 + 2], y[k - i0 - 2]); }
+    else if (n == 2) mac2_const(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]);
+    else if (n == 1) mac_const(acc, x[i0], y[k - i0]);
+  }
+}
+
 template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
 ZG_HD auto add(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
   using K = K29<P>;
@@ -277,16 +350,10 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul(const E29<P, VA, LA>& a, const E29<P, VB, LB>
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 2 * NL - 1; k++) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < NL) mac(acc, a.v[i], b.v[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (i < k && j >= 1 && j < NL) mac_const(acc, m[i], K::PL.v[j]);
-    }
+    // a_i b_(k-i), i in [max(0, k-NL+1), min(k, NL-1)];  m_i p_(k-i), i in [max(0, k-NL+1), min(k-1, NL-1)]
+    const int lo = k - NL + 1 > 0 ? k - NL + 1 : 0;
+    mac_column<NL>(acc, a.v, b.v, k, lo, k < NL - 1 ? k : NL - 1);
+    mac_column_const<NL>(acc, m, K::PL.v, k, lo, k - 1 < NL - 1 ? k - 1 : NL - 1);
     if (k < NL) {
       m[k] = ((uint32_t)acc * K::INV) & K::MASK;
       mac_const(acc, m[k], K::PL.v[0]);
