@@ -214,7 +214,7 @@ ZG_HD void mac4(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b
 ZG_HD void mac2_const(uint64_t& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1) {
 #if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM && ZG_F29_ASM_BLOCKS
   uint64_t co;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=s"(co) : "v"(a0), "s"(k0), "v"(a1), "s"(k1));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=&s"(co) : "v"(a0), "s"(k0), "v"(a1), "s"(k1));
 #else
   mac_const(acc, a0, k0);
   mac_const(acc, a1, k1);
@@ -224,7 +224,7 @@ ZG_HD void mac4_const(uint64_t& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint
 #if defined(__HIP_DEVICE_COMPILE__) && ZG_F29_ASM && ZG_F29_ASM_BLOCKS
   uint64_t co;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-      : "+v"(acc), "=s"(co)
+      : "+v"(acc), "=&s"(co)  // early clobber: the first instruction writes it while later ones still read their k
       : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3));
 #else
   mac2_const(acc, a0, k0, a1, k1);
