@@ -80,7 +80,7 @@ int zg_ctx_create(int device, zg_ctx** out) { return zg_ctx_create_prio(device, 
 
 }  // extern "C"
 
-// prio > 0: highest stream priority (a context's main stream: the latency-critical chain), prio < 0: lowest (side lanes)
+// prio > 0: highest stream priority, prio == 0: the default priority, prio < 0: lowest
 int zg_ctx_create_prio(int device, int prio, zg_ctx** out) {
   if (!out) return ZG_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -94,7 +94,7 @@ int zg_ctx_create_prio(int device, int prio, zg_ctx** out) {
   c->device = device;
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-  hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio > 0 ? greatest : least);
+  hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio > 0 ? greatest : (prio == 0 ? (least + greatest) / 2 : least));
   if (e != hipSuccess) {
     delete c;
     return ZG_ERR_HIP;

@@ -266,7 +266,10 @@ struct ProvingKeyDev : PkBase {
       // reductions were 37 % of a proof's vector instructions), worth +10 % proofs/s with four proofs in flight.
       static const int lane_t = getenv("ZG_PROVE_LANE_SEGMENTS") ? atoi(getenv("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knob
       l->reduce_segments = (lane_t > 0 && (lane_t & (lane_t - 1)) == 0) ? (uint32_t)lane_t : 0u;
-    }  // equal priority: strict priorities starve the lanes
+    }  // the SAME priority as the main stream.  With the lanes one level below it (default or lowest priority, both tried,
+       // rounds 1 and 2) a proof does not complete within 90 s: no fault, the process stays killable, and with equal
+       // priorities the same queue of work takes 4 ms -- the lanes' queues are not served while the high-priority queue
+       // exists, even when it is idle.  Cause inside the runtime's queue scheduling not found; not pursued.
     ZG_HIP(hipEventCreateWithFlags(&w_ready, hipEventDisableTiming));
     ZG_HIP(hipMalloc((void**)&w, (num_vars + 1) * sizeof(Fr)));
     // the three evaluation vectors are one allocation, m elements apart, and so is the transform buffer: the transforms
