@@ -232,29 +232,36 @@ ZG_HD void mac4_const(uint64_t& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint
 #endif
 }
 
-// acc += sum over i in [lo, hi] of x[i] * y[k - i]  (one column's share of a product), in blocks of four
-template <int NLIMBS>
-ZG_HD void mac_column(uint64_t& acc, const uint32_t (&x)[NLIMBS], const uint32_t (&y)[NLIMBS], int k, int lo, int hi) {
-#pragma unroll
-  for (int i = 0; i < NLIMBS; i += 4) {
-    const int i0 = lo + i;
-    const int n = hi - i0 + 1;
-    if (n >= 4) mac4(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1], x[i0 + 2], y[k - i0 - 2], x[i0 + 3], y[k - i0 - 3]);
-    else if (n == 3) { mac2(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]); mac(acc, x[i0 + 2], y[k - i0 - 2]); }
-    else if (n == 2) mac2(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]);
-    else if (n == 1) mac(acc, x[i0], y[k - i0]);
+// acc += sum over i in [I0, HI] of x[i] * y[K - i]  (one column's share of a product), in blocks of four.  The indices
+// are template arguments: as loop variables the 14-limb field's columns were left with dynamic register indexing.
+template <int I0, int HI, int K, int NLIMBS>
+ZG_HD void mac_column(uint64_t& acc, const uint32_t (&x)[NLIMBS], const uint32_t (&y)[NLIMBS]) {
+  constexpr int n = HI - I0 + 1;
+  if constexpr (n >= 4) {
+    mac4(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1], x[I0 + 2], y[K - I0 - 2], x[I0 + 3], y[K - I0 - 3]);
+    mac_column<I0 + 4, HI, K, NLIMBS>(acc, x, y);
+  } else if constexpr (n == 3) {
+    mac2(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1]);
+    mac(acc, x[I0 + 2], y[K - I0 - 2]);
+  } else if constexpr (n == 2) {
+    mac2(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1]);
+  } else if constexpr (n == 1) {
+    mac(acc, x[I0], y[K - I0]);
   }
 }
-template <int NLIMBS>
-ZG_HD void mac_column_const(uint64_t& acc, const uint32_t (&x)[NLIMBS], const uint32_t (&y)[NLIMBS], int k, int lo, int hi) {
-#pragma unroll
-  for (int i = 0; i < NLIMBS; i += 4) {
-    const int i0 = lo + i;
-    const int n = hi - i0 + 1;
-    if (n >= 4) mac4_const(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1], x[i0 + 2], y[k - i0 - 2], x[i0 + 3], y[k - i0 - 3]);
-    else if (n == 3) { mac2_const(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]); mac_const(acc, x[i0 + 2], y[k - i0 - 2]); }
-    else if (n == 2) mac2_const(acc, x[i0], y[k - i0], x[i0 + 1], y[k - i0 - 1]);
-    else if (n == 1) mac_const(acc, x[i0], y[k - i0]);
+template <int I0, int HI, int K, int NLIMBS>
+ZG_HD void mac_column_const(uint64_t& acc, const uint32_t (&x)[NLIMBS], const uint32_t (&y)[NLIMBS]) {
+  constexpr int n = HI - I0 + 1;
+  if constexpr (n >= 4) {
+    mac4_const(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1], x[I0 + 2], y[K - I0 - 2], x[I0 + 3], y[K - I0 - 3]);
+    mac_column_const<I0 + 4, HI, K, NLIMBS>(acc, x, y);
+  } else if constexpr (n == 3) {
+    mac2_const(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1]);
+    mac_const(acc, x[I0 + 2], y[K - I0 - 2]);
+  } else if constexpr (n == 2) {
+    mac2_const(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1]);
+  } else if constexpr (n == 1) {
+    mac_const(acc, x[I0], y[K - I0]);
   }
 }
 
@@ -338,30 +345,34 @@ ZG_HD E29<P, VA, LA> select(const E29<P, VA, LA>& a, const E29<P, VA, LA>& b, bo
 
 // Montgomery product a b / R' + (multiple of p), by columns: column k collects a_i b_j and m_i p_j with i + j = k in
 // one 64-bit accumulator, m_k clears its low B bits, the rest moves to column k + 1.  Result < 2 p, limbs normalised.
+template <class P, int K_, class A, class Bt>
+ZG_HD void mul_columns_from(uint64_t& acc, const A& a, const Bt& b, uint32_t (&m)[K29<P>::NL], E29<P, 2, K29<P>::LNORM>& r) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  // a_i b_(k-i), i in [max(0, k-NL+1), min(k, NL-1)];  m_i p_(k-i), i in [max(0, k-NL+1), min(k-1, NL-1)]
+  constexpr int lo = K_ - NL + 1 > 0 ? K_ - NL + 1 : 0;
+  mac_column<lo, (K_ < NL - 1 ? K_ : NL - 1), K_, NL>(acc, a.v, b.v);
+  mac_column_const<lo, (K_ - 1 < NL - 1 ? K_ - 1 : NL - 1), K_, NL>(acc, m, K::PL.v);
+  if constexpr (K_ < NL) {
+    m[K_] = ((uint32_t)acc * K::INV) & K::MASK;
+    mac_const(acc, m[K_], K::PL.v[0]);
+  } else {
+    r.v[K_ - NL] = (uint32_t)acc & K::MASK;
+  }
+  acc >>= B;
+  if constexpr (K_ + 1 < 2 * NL - 1) mul_columns_from<P, K_ + 1>(acc, a, b, m, r);
+}
 template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
 ZG_HD E29<P, 2, K29<P>::LNORM> mul(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
   using K = K29<P>;
-  constexpr int NL = K::NL, B = K::B;
+  constexpr int NL = K::NL;
   // column sum: NL products of limbs (top limbs are value-bounded and far smaller) + NL products m_i p_j + carry-in
   static_assert(K::column_fits(VA, LA, VB, LB), "mul: a column overflows 64 bits -- carry() an operand first");
   static_assert(VA * VB <= K::mont_room(), "mul: operands too large for a result below 2 p");
   uint32_t m[NL];
   E29<P, 2, K::LNORM> r;
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * NL - 1; k++) {
-    // a_i b_(k-i), i in [max(0, k-NL+1), min(k, NL-1)];  m_i p_(k-i), i in [max(0, k-NL+1), min(k-1, NL-1)]
-    const int lo = k - NL + 1 > 0 ? k - NL + 1 : 0;
-    mac_column<NL>(acc, a.v, b.v, k, lo, k < NL - 1 ? k : NL - 1);
-    mac_column_const<NL>(acc, m, K::PL.v, k, lo, k - 1 < NL - 1 ? k - 1 : NL - 1);
-    if (k < NL) {
-      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
-      mac_const(acc, m[k], K::PL.v[0]);
-    } else {
-      r.v[k - NL] = (uint32_t)acc & K::MASK;
-    }
-    acc >>= B;
-  }
+  mul_columns_from<P, 0>(acc, a, b, m, r);
   r.v[NL - 1] = (uint32_t)acc;
   return r;
 }
