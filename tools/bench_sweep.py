@@ -103,6 +103,9 @@ def main():
         msm_case(ctx, 0, 2, 22)
         msm_case(ctx, 1, 1, 22)
         msm_case(ctx, 1, 2, 20)
+    if which == "nttsizes":  # nttsizes LOG_M...
+        for a in sys.argv[2:]:
+            ntt_case(ctx, 0, int(a))
     if which == "ntt1":  # one size, for profiling: ntt1 LOG_M [REPS]
         ntt_case(ctx, 0, int(sys.argv[2]), reps=int(sys.argv[3]) if len(sys.argv) > 3 else 5)
     if which in ("all", "ntt"):

@@ -38,11 +38,15 @@ inline Fr host_pow_u64(Fr b, uint64_t e) {
   return r;
 }
 
-inline uint32_t ntt_tile_elems() {  // elements of a workgroup's tile; ZG_NTT_TILE_ELEMS = 2048 | 4096 (tuning knob)
+// Elements of a workgroup's tile where a pass's transforms fit it: 2048 (74 KB of LDS) lets TWO workgroups share a CU,
+// so one's loads and stores overlap the other's stages -- 2^22: 0.50 against 0.53 ms with 4096-element tiles, 2^21: 0.26
+// against 0.275; passes of 4096-point transforms (m >= 2^23) need the full 4096.  ZG_NTT_TILE_ELEMS = 2048 | 4096 (tuning
+// knob).
+inline uint32_t ntt_tile_elems() {
   static const uint32_t v = [] {
     const char* e = getenv("ZG_NTT_TILE_ELEMS");
     const uint32_t x = e ? (uint32_t)atoi(e) : 0u;
-    return (x == 2048u || x == 4096u) ? x : (uint32_t)NTT_LDS_ELEMS;
+    return (x == 2048u || x == 4096u) ? x : 2048u;
   }();
   return v;
 }
