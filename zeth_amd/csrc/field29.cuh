@@ -379,39 +379,36 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul(const E29<P, VA, LA>& a, const E29<P, VB, LB>
 
 // a b + c d in ONE Montgomery reduction: the columns of both products share their accumulators, so the second product
 // costs its NL^2 limb products but no second round of m_i p_j (a third of a product's multiplies).  Result < 2 p.
+template <class P, int K_, class A, class Bt, class C, class D>
+ZG_HD void mul_add_columns_from(uint64_t& acc, const A& a, const Bt& b, const C& c, const D& d, uint32_t (&m)[K29<P>::NL],
+                                E29<P, 2, K29<P>::LNORM>& r) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  constexpr int lo = K_ - NL + 1 > 0 ? K_ - NL + 1 : 0;
+  constexpr int hi = K_ < NL - 1 ? K_ : NL - 1;
+  mac_column<lo, hi, K_, NL>(acc, a.v, b.v);
+  mac_column<lo, hi, K_, NL>(acc, c.v, d.v);
+  mac_column_const<lo, (K_ - 1 < NL - 1 ? K_ - 1 : NL - 1), K_, NL>(acc, m, K::PL.v);
+  if constexpr (K_ < NL) {
+    m[K_] = ((uint32_t)acc * K::INV) & K::MASK;
+    mac_const(acc, m[K_], K::PL.v[0]);
+  } else {
+    r.v[K_ - NL] = (uint32_t)acc & K::MASK;
+  }
+  acc >>= B;
+  if constexpr (K_ + 1 < 2 * NL - 1) mul_add_columns_from<P, K_ + 1>(acc, a, b, c, d, m, r);
+}
 template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB, uint64_t VC, uint64_t LC, uint64_t VD, uint64_t LD>
 ZG_HD E29<P, 2, K29<P>::LNORM> mul_add(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b, const E29<P, VC, LC>& c,
                                        const E29<P, VD, LD>& d) {
   using K = K29<P>;
-  constexpr int NL = K::NL, B = K::B;
+  constexpr int NL = K::NL;
   static_assert(K::column_fits2(VA, LA, VB, LB, VC, LC, VD, LD), "mul_add: a column overflows 64 bits -- carry() an operand first");
   static_assert(VA * VB + VC * VD <= K::mont_room(), "mul_add: operands too large for a result below 2 p");
   uint32_t m[NL];
   E29<P, 2, K::LNORM> r;
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * NL - 1; k++) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < NL) {
-        mac(acc, a.v[i], b.v[j]);
-        mac(acc, c.v[i], d.v[j]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (i < k && j >= 1 && j < NL) mac_const(acc, m[i], K::PL.v[j]);
-    }
-    if (k < NL) {
-      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
-      mac_const(acc, m[k], K::PL.v[0]);
-    } else {
-      r.v[k - NL] = (uint32_t)acc & K::MASK;
-    }
-    acc >>= B;
-  }
+  mul_add_columns_from<P, 0>(acc, a, b, c, d, m, r);
   r.v[NL - 1] = (uint32_t)acc;
   return r;
 }
@@ -525,10 +522,29 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul_add4(const E29<P, V1, L1>& a1, const E29<P, W
 }
 
 // a^2: the cross products once, against the doubled operand
+template <class P, int K_, class A>
+ZG_HD void sqr_columns_from(uint64_t& acc, const A& a, const uint32_t (&a2)[K29<P>::NL], uint32_t (&m)[K29<P>::NL],
+                            E29<P, 2, K29<P>::LNORM>& r) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  constexpr int lo = K_ - NL + 1 > 0 ? K_ - NL + 1 : 0;
+  // 2 a_i a_(k-i) for i < k - i, then a_(k/2)^2 on even columns
+  mac_column<lo, (K_ - 1) / 2 - (K_ == 0 ? 1 : 0), K_, NL>(acc, a2, a.v);
+  if constexpr (K_ % 2 == 0) mac(acc, a.v[K_ / 2], a.v[K_ / 2]);
+  mac_column_const<lo, (K_ - 1 < NL - 1 ? K_ - 1 : NL - 1), K_, NL>(acc, m, K::PL.v);
+  if constexpr (K_ < NL) {
+    m[K_] = ((uint32_t)acc * K::INV) & K::MASK;
+    mac_const(acc, m[K_], K::PL.v[0]);
+  } else {
+    r.v[K_ - NL] = (uint32_t)acc & K::MASK;
+  }
+  acc >>= B;
+  if constexpr (K_ + 1 < 2 * NL - 1) sqr_columns_from<P, K_ + 1>(acc, a, a2, m, r);
+}
 template <class P, uint64_t VA, uint64_t LA>
 ZG_HD E29<P, 2, K29<P>::LNORM> sqr(const E29<P, VA, LA>& a) {
   using K = K29<P>;
-  constexpr int NL = K::NL, B = K::B;
+  constexpr int NL = K::NL;
   static_assert(K::column_fits(VA, LA, VA, LA), "sqr: a column overflows 64 bits -- carry() the operand first");
   static_assert(VA * VA <= K::mont_room(), "sqr: operand too large for a result below 2 p");
   static_assert(2 * LA < (1ull << 32), "sqr: doubled limb overflow");
@@ -537,27 +553,7 @@ ZG_HD E29<P, 2, K29<P>::LNORM> sqr(const E29<P, VA, LA>& a) {
   for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
   E29<P, 2, K::LNORM> r;
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * NL - 1; k++) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j > i && j < NL) mac(acc, a2[i], a.v[j]);
-      if (j == i) mac(acc, a.v[i], a.v[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (i < k && j >= 1 && j < NL) mac_const(acc, m[i], K::PL.v[j]);
-    }
-    if (k < NL) {
-      m[k] = ((uint32_t)acc * K::INV) & K::MASK;
-      mac_const(acc, m[k], K::PL.v[0]);
-    } else {
-      r.v[k - NL] = (uint32_t)acc & K::MASK;
-    }
-    acc >>= B;
-  }
+  sqr_columns_from<P, 0>(acc, a, a2, m, r);
   r.v[NL - 1] = (uint32_t)acc;
   return r;
 }
