@@ -264,8 +264,10 @@ struct ProvingKeyDev : PkBase {
       // The lanes' evaluations are off the proof's critical path (the H chain on the main stream): 128 bucket segments a
       // window instead of 1024 cut their reduction's instruction count 2.6x (profiles/r2_prove_valu_by_kernel.txt: the
       // reductions were 37 % of a proof's vector instructions), worth +10 % proofs/s with four proofs in flight.
-      static const int lane_t = getenv("ZG_PROVE_LANE_SEGMENTS") ? atoi(getenv("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knob
-      l->reduce_segments = (lane_t > 0 && (lane_t & (lane_t - 1)) == 0) ? (uint32_t)lane_t : 0u;
+      static const int lane_t = getenv("ZG_PROVE_LANE_SEGMENTS") ? atoi(getenv("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knobs
+      static const int lane_t_g2 = getenv("ZG_PROVE_G2_SEGMENTS") ? atoi(getenv("ZG_PROVE_G2_SEGMENTS")) : 256;
+      const int t = (&l == &lane[0]) ? lane_t_g2 : lane_t;  // lane 0 runs the G2 evaluation, whose additions cost 3x
+      l->reduce_segments = (t > 0 && (t & (t - 1)) == 0) ? (uint32_t)t : 0u;
     }  // the SAME priority as the main stream.  With the lanes one level below it (default or lowest priority, both tried,
        // rounds 1 and 2) a proof does not complete within 90 s: no fault, the process stays killable, and with equal
        // priorities the same queue of work takes 4 ms -- the lanes' queues are not served while the high-priority queue
