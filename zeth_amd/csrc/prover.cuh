@@ -331,23 +331,29 @@ struct ProvingKeyDev : PkBase {
     return ZG_OK;
   }
 
-  // constraint evaluation, the seven transforms and the pointwise pass: H's coefficients end up in `tmp`
-  int qap_h() {
+  // constraint evaluation, the seven transforms and the pointwise pass: H's coefficients end up in `tmp`.  Three parts
+  // (0: constraint evaluation + iFFTs, 1: cosetFFTs, 2: pointwise + icosetFFT) so that the prover can place an event
+  // between them.
+  int qap_h(int first_part = 0, int last_part = 2) {
     hipStream_t st = ctx->stream;
     const unsigned mb = (unsigned)((m + 255) / 256);
-    SpmvMatrices M;
-    for (int k = 0; k < 3; k++) {
-      M.row_ptr[k] = mat[k].row_ptr;
-      M.col[k] = mat[k].col;
-      M.val[k] = mat[k].val;
-    }
-    hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb, 3), dim3(256), 0, st, M, (const Fr*)w, nc, m, num_inputs + 1, ev[0]);
     NttDomain<Fr>* D = nullptr;
     ZG_TRY(ntt_get_domain<Fr>(ctx, curve, log_m, &D));
-    ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 0, 3, m));  // iFFT of A, B, C
-    ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[0], 0, 1, 3, m));  // cosetFFT of A, B, C
-    hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
-    ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
+    if (first_part <= 0 && last_part >= 0) {
+      SpmvMatrices M;
+      for (int k = 0; k < 3; k++) {
+        M.row_ptr[k] = mat[k].row_ptr;
+        M.col[k] = mat[k].col;
+        M.val[k] = mat[k].val;
+      }
+      hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb, 3), dim3(256), 0, st, M, (const Fr*)w, nc, m, num_inputs + 1, ev[0]);
+      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 0, 3, m));  // iFFT of A, B, C
+    }
+    if (first_part <= 1 && last_part >= 1) ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[0], 0, 1, 3, m));  // cosetFFT of A, B, C
+    if (first_part <= 2 && last_part >= 2) {
+      hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
+      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
+    }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
   }
@@ -365,6 +371,11 @@ struct ProvingKeyDev : PkBase {
     if (B_len) hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
     // The A, B (G2 and G1) and L evaluations depend only on 1||w: they run on four side streams ("lanes", each a
     // context with its own workspace) while the main stream computes H's coefficients and then the H evaluation.
+    // ZG_PROVE_HOLD = 1 | 2 | 3 (measurement knob): the lanes start only after that many parts of the H chain's
+    // transforms have run (0: as soon as 1||w is there)
+    static const int hold = getenv("ZG_PROVE_HOLD") ? atoi(getenv("ZG_PROVE_HOLD")) : 0;
+    int h_status = ZG_OK;
+    if (hold >= 1 && hold <= 3) h_status = qap_h(0, hold - 1);
     ZG_HIP(hipEventRecord(w_ready, st));
     for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
     const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
@@ -408,7 +419,7 @@ struct ProvingKeyDev : PkBase {
         }
       }
     }
-    int h_status = qap_h();
+    if (h_status == ZG_OK && !(hold >= 3)) h_status = qap_h(hold >= 1 && hold <= 3 ? hold : 0, 2);
     const MsmTable h_tab{H_len, 0, H_c, H_levels};
     if (h_status == ZG_OK) h_status = o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr);
     for (int i = 0; i < 4; i++) {
