@@ -121,7 +121,33 @@ static __global__ void __launch_bounds__(1024) k_hist_table(const uint16_t* __re
   const uint32_t per = (end - start + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = start + blockIdx.x * per < end ? start + blockIdx.x * per : end;
   const uint32_t hi = lo + per < end ? lo + per : end;
-  for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&lh[fkey[q]], 1u);
+  // the bulk eight keys (16 bytes) per lane and load, two loads in flight; the unaligned ends one key per lane
+  const uint32_t lo8 = (lo + 7u) & ~7u, hi8 = hi & ~7u;
+  if (lo8 < hi8) {
+    for (uint32_t q = lo + threadIdx.x; q < lo8; q += blockDim.x) atomicAdd(&lh[fkey[q]], 1u);
+    const uint4* v = reinterpret_cast<const uint4*>(fkey + lo8);
+    const uint32_t nv = (hi8 - lo8) >> 3;
+    auto count = [&](const uint4& k) {
+      atomicAdd(&lh[k.x & 0xFFFFu], 1u);
+      atomicAdd(&lh[k.x >> 16], 1u);
+      atomicAdd(&lh[k.y & 0xFFFFu], 1u);
+      atomicAdd(&lh[k.y >> 16], 1u);
+      atomicAdd(&lh[k.z & 0xFFFFu], 1u);
+      atomicAdd(&lh[k.z >> 16], 1u);
+      atomicAdd(&lh[k.w & 0xFFFFu], 1u);
+      atomicAdd(&lh[k.w >> 16], 1u);
+    };
+    uint32_t i = threadIdx.x;
+    for (; i + blockDim.x < nv; i += 2 * blockDim.x) {
+      const uint4 k0 = v[i], k1 = v[i + blockDim.x];
+      count(k0);
+      count(k1);
+    }
+    if (i < nv) count(v[i]);
+    for (uint32_t q = hi8 + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&lh[fkey[q]], 1u);
+  } else {
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&lh[fkey[q]], 1u);
+  }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
     const uint32_t v = lh[b];
