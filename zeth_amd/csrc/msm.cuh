@@ -478,8 +478,13 @@ static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restri
 // straight into 2^15 bucket streams writes 4-byte entries to 2^15 different cache lines per block (measured 6.7 ms
 // at 2^24 points); here level 1 splits a tile over <= 128 partitions of 256 buckets (runs of ~128 entries) and level 2
 // finishes each partition on its low 8 bits (runs of ~32 entries), so both levels write in long contiguous runs.
-static constexpr uint32_t SORT_TILE1 = 8192;
-static constexpr uint32_t SORT_TILE2 = 8192;
+#ifndef ZG_SORT_WG
+#define ZG_SORT_WG 1024
+#endif
+static constexpr uint32_t SORT_WG = ZG_SORT_WG;      // lanes of k_scatter_hi_table and k_scatter_lo, eight entries each
+static constexpr uint32_t SORT_TILE1 = 8192;         // k_scatter_hi (1024 lanes)
+static constexpr uint32_t SORT_TILE1T = 8 * SORT_WG; // k_scatter_hi_table
+static constexpr uint32_t SORT_TILE2 = 8 * SORT_WG;  // k_scatter_lo
 
 // Both levels sort their tile inside LDS first (histogram, exclusive scan, ranked placement) and then copy the LDS
 // image out linearly, so that a wave writes 64 consecutive entries of (mostly) one run: full-line global stores.
@@ -547,7 +552,7 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
 }
 
 // grid (tiles, nhi, W): partition p of window w, tiles taken grid-stride so that any distribution is covered
-static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __restrict__ mid_ent,
+static __global__ void __launch_bounds__(SORT_WG) k_scatter_lo(const uint32_t* __restrict__ mid_ent,
                                                      const uint8_t* __restrict__ mid_lo,
                                                      const uint32_t* __restrict__ pstart, uint32_t nhi, uint32_t nb,
                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
@@ -558,25 +563,35 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
   const uint32_t p = blockIdx.y, w = w0 + blockIdx.z;
   const uint32_t start = pstart[(size_t)w * (nhi + 1) + p], end = pstart[(size_t)w * (nhi + 1) + p + 1];
   uint32_t* cur = cursor + (size_t)w * nb + (size_t)p * 256;
-  for (uint32_t lo = start + blockIdx.x * SORT_TILE2; lo < end; lo += gridDim.x * SORT_TILE2) {
+  // tiles on multiples of eight entries, eight consecutive entries per lane (see k_scatter_hi_table)
+  for (uint32_t lo = (start & ~7u) + blockIdx.x * SORT_TILE2; lo < end; lo += gridDim.x * SORT_TILE2) {
     uint32_t hi = lo + SORT_TILE2;
     if (hi > end) hi = end;
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     // one pass over the tile: every lane keeps its (up to) 8 entries and their ranks within their bins in registers, so
     // each entry costs one LDS atomic and one read of the intermediate arrays
-    constexpr uint32_t PER = SORT_TILE2 / 1024;
+    constexpr uint32_t PER = SORT_TILE2 / SORT_WG;
+    static_assert(PER == 8, "eight entries per lane: one uint2 of bins, two uint4 of entries");
     uint32_t my_ent[PER], my_rank[PER];
     uint32_t my_bin[PER];
+    const uint32_t q0 = lo + threadIdx.x * PER;
+    if (q0 < hi) {  // reads up to seven entries past `end`: inside the workspace
+      const uint2 b = *reinterpret_cast<const uint2*>(mid_lo + q0);
+      const uint4 e0 = *reinterpret_cast<const uint4*>(mid_ent + q0);
+      const uint4 e1 = *reinterpret_cast<const uint4*>(mid_ent + q0 + 4);
+      my_bin[0] = b.x & 255u, my_bin[1] = (b.x >> 8) & 255u, my_bin[2] = (b.x >> 16) & 255u, my_bin[3] = b.x >> 24;
+      my_bin[4] = b.y & 255u, my_bin[5] = (b.y >> 8) & 255u, my_bin[6] = (b.y >> 16) & 255u, my_bin[7] = b.y >> 24;
+      my_ent[0] = e0.x, my_ent[1] = e0.y, my_ent[2] = e0.z, my_ent[3] = e0.w;
+      my_ent[4] = e1.x, my_ent[5] = e1.y, my_ent[6] = e1.z, my_ent[7] = e1.w;
+    }
 #pragma unroll
     for (uint32_t r = 0; r < PER; r++) {
-      const uint32_t i = lo + r * 1024u + threadIdx.x;
-      my_bin[r] = 0xFFFFFFFFu;
-      if (i < hi) {
-        my_bin[r] = mid_lo[i];
-        my_ent[r] = mid_ent[i];
+      const uint32_t i = q0 + r;
+      if (i >= start && i < hi)
         my_rank[r] = atomicAdd(&h[my_bin[r]], 1u);
-      }
+      else
+        my_bin[r] = 0xFFFFFFFFu;
     }
     __syncthreads();
     {
@@ -606,7 +621,7 @@ static __global__ void __launch_bounds__(1024) k_scatter_lo(const uint32_t* __re
       }
     }
     __syncthreads();
-    const uint32_t total = hi - lo;
+    const uint32_t total = hi - (lo > start ? lo : start);
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
       uint32_t bin = buf_bin[i];
       sorted[gbase[bin] + (i - lstart[bin])] = buf_ent[i];

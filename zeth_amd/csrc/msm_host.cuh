@@ -290,15 +290,15 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   auto scatter_group = [&](hipStream_t s, uint32_t w0, uint32_t cntw) {
     if (tab) {
       if (nhi) {
-        size_t t1 = (2 * per_group + SORT_TILE1 - 1) / SORT_TILE1;
+        size_t t1 = (2 * per_group + SORT_TILE1T - 1) / SORT_TILE1T;
         if (t1 < 1) t1 = 1;
-        if (t1 > 4096) t1 = 4096;
-        hipLaunchKernelGGL(k_scatter_hi_table, dim3((unsigned)t1, cntw), dim3(1024), 0, s, fent, fkey, gstart, nhi, cursor1, mid_ent,
+        if (t1 > 8192) t1 = 8192;
+        hipLaunchKernelGGL(k_scatter_hi_table, dim3((unsigned)t1, cntw), dim3(SORT_WG), 0, s, fent, fkey, gstart, nhi, cursor1, mid_ent,
                            mid_lo);
         size_t tiles = (2 * per_group / nhi + SORT_TILE2 - 1) / SORT_TILE2;
         if (tiles < 1) tiles = 1;
         if (tiles > 64) tiles = 64;
-        hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, cntw), dim3(1024), 0, s, mid_ent, mid_lo, pstart, nhi, p.nb,
+        hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, cntw), dim3(SORT_WG), 0, s, mid_ent, mid_lo, pstart, nhi, p.nb,
                            cursor, sorted, w0);
       } else {
         hipLaunchKernelGGL(k_scatter_table, dim3(p.nchunk, p.W), dim3(1024), lds, s, fent, fkey, gstart, p.nb, cursor, sorted);
@@ -309,7 +309,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
       size_t tiles = (2 * n / nhi + SORT_TILE2 - 1) / SORT_TILE2;
       if (tiles < 1) tiles = 1;
       if (tiles > 64) tiles = 64;
-      hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, cntw), dim3(1024), 0, s, mid_ent, mid_lo, pstart, nhi, p.nb,
+      hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, cntw), dim3(SORT_WG), 0, s, mid_ent, mid_lo, pstart, nhi, p.nb,
                          cursor, sorted, w0);
     } else {
       hipLaunchKernelGGL(k_scatter, dim3(p.nchunk, p.W), dim3(1024), lds, s, dig, n, p.nb, p.nchunk, cursor, sorted);

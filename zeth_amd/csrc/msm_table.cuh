@@ -180,31 +180,43 @@ static __global__ void __launch_bounds__(1024) k_scatter_table(const uint32_t* _
 
 // k_scatter_hi's counterpart: tiles of a group's (entry, key) list split over the group's partitions of 256 buckets;
 // grid (tile slots, W), tiles taken grid-stride so that a group holding most entries is still covered
-static __global__ void __launch_bounds__(1024) k_scatter_hi_table(const uint32_t* __restrict__ fent, const uint16_t* __restrict__ fkey,
+static __global__ void __launch_bounds__(SORT_WG) k_scatter_hi_table(const uint32_t* __restrict__ fent, const uint16_t* __restrict__ fkey,
                                                                   const uint32_t* __restrict__ gstart, uint32_t nhi,
                                                                   uint32_t* __restrict__ cursor1, uint32_t* __restrict__ mid_ent,
                                                                   uint8_t* __restrict__ mid_lo) {
   __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
-  __shared__ uint32_t buf_ent[SORT_TILE1];
-  __shared__ uint8_t buf_lo[SORT_TILE1], buf_bin[SORT_TILE1];
+  __shared__ uint32_t buf_ent[SORT_TILE1T];
+  __shared__ uint8_t buf_lo[SORT_TILE1T], buf_bin[SORT_TILE1T];
   const uint32_t w = blockIdx.y;
   const uint32_t start = gstart[w], end = gstart[w + 1];
-  for (uint32_t lo = start + blockIdx.x * SORT_TILE1; lo < end; lo += gridDim.x * SORT_TILE1) {
-    const uint32_t hi = lo + SORT_TILE1 < end ? lo + SORT_TILE1 : end;
+  // Tiles start on multiples of eight entries (the first one below `start`, its leading entries masked), so that a lane
+  // takes eight consecutive entries with one 16-byte load of keys and two of entries: with one narrow load per entry the
+  // kernel waited on load latency, not bandwidth.  Which lane ranks which entry does not matter to a counting sort.
+  for (uint32_t lo = (start & ~7u) + blockIdx.x * SORT_TILE1T; lo < end; lo += gridDim.x * SORT_TILE1T) {
+    const uint32_t hi = lo + SORT_TILE1T < end ? lo + SORT_TILE1T : end;
     if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
     // one pass: entries, keys and ranks within their bins stay in registers (one LDS atomic per entry)
-    constexpr uint32_t PER = SORT_TILE1 / 1024;
+    constexpr uint32_t PER = SORT_TILE1T / SORT_WG;
+    static_assert(PER == 8, "eight entries per lane: one uint4 of keys, two of entries");
     uint32_t my_ent[PER], my_key[PER], my_rank[PER];
+    const uint32_t q0 = lo + threadIdx.x * PER;
+    if (q0 < hi) {  // reads up to seven entries past `end`: inside the workspace (every array is followed by another)
+      const uint4 k = *reinterpret_cast<const uint4*>(fkey + q0);
+      const uint4 e0 = *reinterpret_cast<const uint4*>(fent + q0);
+      const uint4 e1 = *reinterpret_cast<const uint4*>(fent + q0 + 4);
+      my_key[0] = k.x & 0xFFFFu, my_key[1] = k.x >> 16, my_key[2] = k.y & 0xFFFFu, my_key[3] = k.y >> 16;
+      my_key[4] = k.z & 0xFFFFu, my_key[5] = k.z >> 16, my_key[6] = k.w & 0xFFFFu, my_key[7] = k.w >> 16;
+      my_ent[0] = e0.x, my_ent[1] = e0.y, my_ent[2] = e0.z, my_ent[3] = e0.w;
+      my_ent[4] = e1.x, my_ent[5] = e1.y, my_ent[6] = e1.z, my_ent[7] = e1.w;
+    }
 #pragma unroll
     for (uint32_t r = 0; r < PER; r++) {
-      const uint32_t q = lo + r * 1024u + threadIdx.x;
-      my_key[r] = 0xFFFFFFFFu;
-      if (q < hi) {
-        my_key[r] = fkey[q];
-        my_ent[r] = fent[q];
+      const uint32_t q = q0 + r;
+      if (q >= start && q < hi)
         my_rank[r] = atomicAdd(&h[my_key[r] >> 8], 1u);
-      }
+      else
+        my_key[r] = 0xFFFFFFFFu;
     }
     __syncthreads();
     uint32_t v = 0, incl = 0;
@@ -230,7 +242,7 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi_table(const uint32_t
       }
     }
     __syncthreads();
-    const uint32_t total = hi - lo;
+    const uint32_t total = hi - (lo > start ? lo : start);
     for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
       const uint32_t bin = buf_bin[q];
       const uint32_t g = gbase[bin] + (q - lstart[bin]);
