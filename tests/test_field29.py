@@ -29,3 +29,33 @@ def test_selftest_rejects_unknown_field():
     L.zg_selftest_reduced_radix.restype = ctypes.c_int
     bad = ctypes.c_int(0)
     assert L.zg_selftest_reduced_radix(ctypes.c_int(9), ctypes.c_int(1), ctypes.c_uint64(1), ctypes.byref(bad)) == -1
+
+
+QUAD_GROUPS = {0: "alt_bn128 G1", 1: "BLS12-377 G1", 2: "alt_bn128 G2", 3: "BLS12-377 G2"}
+
+
+@pytest.mark.parametrize("group", sorted(QUAD_GROUPS))
+def test_quad_lane_point_arithmetic_matches_one_lane_formulas(group):
+    """curve_quad.cuh / curve_quad29.cuh (the additions of k_combine_* and k_reduce*) on the host, four threads standing
+    in for the four lanes of a quad: distinct points, P + P, P - P, the identity on either side, running sums, doublings
+    and the round trip through the kernels' buffer form, against curve.cuh's xyzz_add / xyzz_dbl."""
+    L = zl.load_library()
+    L.zg_selftest_quad_lanes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.zg_selftest_quad_lanes.restype = ctypes.c_int
+    bad = ctypes.c_int(-1)
+    assert L.zg_selftest_quad_lanes(group, ctypes.byref(bad)) == 0
+    assert bad.value == 0, QUAD_GROUPS[group]
+    assert L.zg_selftest_quad_lanes(9, ctypes.byref(bad)) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [0, 1])
+def test_quad_lane_point_arithmetic_on_the_device(group):
+    """The same templates as compiled for gfx950 (32-bit limbs and the reduced radix): 68 additions and doublings with
+    every exceptional case, compared on the host with the one-lane formulas."""
+    L = zl.load_library()
+    L.zg_selftest_quad_lanes_device.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.zg_selftest_quad_lanes_device.restype = ctypes.c_int
+    bad = ctypes.c_int(-1)
+    assert L.zg_selftest_quad_lanes_device(group, ctypes.byref(bad)) == 0
+    assert bad.value == 0, QUAD_GROUPS[group]

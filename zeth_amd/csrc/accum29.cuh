@@ -91,6 +91,19 @@ ZG_HD XYZZ<Fp<P>> acc29_to_xyzz(const Acc29<P>& a) {
   return r;
 }
 
+// x R' mod p in [0, p) in the words of a field element: the form of the buffers the quad kernels exchange
+// (curve_quad29.cuh), where a load is then free of any product
+template <class P>
+ZG_HD XYZZ<Fp<P>> acc29_to_part(const Acc29<P>& a) {
+  const auto o = f29::one<P>();
+  XYZZ<Fp<P>> r;
+  r.x = f29::to_words(f29::canon(f29::mul(a.x, o)));
+  r.y = f29::to_words(f29::canon(f29::mul(a.y, o)));
+  r.zz = f29::to_words(f29::canon(f29::mul(a.zz, o)));
+  r.zzz = f29::to_words(f29::canon(f29::mul(a.zzz, o)));
+  return r;
+}
+
 // 2 (+-)P for an affine P != identity (EFD mdbl-2008-s-1, a = 0)
 template <class P>
 ZG_HD Acc29<P> mdbl29(const Affine<Fp<P>>& p, bool negate) {

@@ -282,6 +282,7 @@ struct AccumOf<Fp<P>> {
   ZG_HD static Acc from_affine(const Affine<Fp<P>>& p, bool n) { return acc29_from_affine<P>(p, n); }
   ZG_HD static Acc madd(const Acc& a, const Affine<Fp<P>>& p, bool n) { return madd29<P>(a, p, n); }
   ZG_HD static XYZZ<Fp<P>> to_xyzz(const Acc& a) { return acc29_to_xyzz<P>(a); }
+  ZG_HD static XYZZ<Fp<P>> to_part(const Acc& a) { return acc29_to_part<P>(a); }
 };
 template <class P, int NR>
 struct AccumOf<Fp2<Fp<P>, NR>> {

@@ -24,35 +24,111 @@
 
 #include "curve.cuh"
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <atomic>
+#include <cstring>
+#include <thread>
+#endif
+
+// Every cross-lane move stays an instruction of its own (an empty asm statement on its result).  Left alone, the compiler
+// folds a move into the subtraction that consumes it (v_subrev_u32_dpp ... quad_perm), which the limb-wise differences
+// of curve_quad29.cuh invite: with those folded instructions the alt_bn128 kernels returned wrong sums on gfx950, while
+// the host build of the same templates, and the device build with the moves kept apart, agree with the one-lane
+// formulas (zg_selftest_quad_lanes / zg_selftest_quad_lanes_device).
+#ifndef ZG_QUAD_DPP_STANDALONE
+#define ZG_QUAD_DPP_STANDALONE 1
+#endif
+
 namespace zg {
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host stand-in for the cross-lane moves, so that the CPU self-test (selftest.hip) runs the very templates the kernels
+// instantiate: the four lanes of ONE quad are four host threads that meet at every exchange.
+struct QuadHost {
+  uint32_t slot[4][64];
+  std::atomic<unsigned> arrived{0}, phase{0};
+  void barrier() {
+    const unsigned ph = phase.load();
+    if (arrived.fetch_add(1) == 3) {
+      arrived.store(0);
+      phase.store(ph + 1);
+    } else {
+      while (phase.load() == ph) std::this_thread::yield();
+    }
+  }
+  template <class T>
+  T exchange(const T& v, int lane, int from) {
+    static_assert(sizeof(T) <= sizeof(slot[0]), "exchange slot too small");
+    memcpy(slot[lane], &v, sizeof(T));
+    barrier();
+    T r;
+    memcpy(&r, slot[from], sizeof(T));
+    barrier();
+    return r;
+  }
+};
+inline QuadHost*& quad_host() {
+  static QuadHost* h = nullptr;
+  return h;
+}
+inline int& quad_host_lane() {
+  thread_local int lane = 0;
+  return lane;
+}
+#endif
 
 // lane i of every quad receives v from lane (CTRL >> 2 i) & 3 of its quad
 template <int CTRL, class F>
-__device__ __forceinline__ F quad_perm(const F& v) {
+ZG_HD F quad_perm(const F& v) {
   static_assert(sizeof(F) % 4 == 0, "field elements are arrays of 32-bit words");
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = sizeof(F) / 4;
   F r;
   const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
   uint32_t* d = reinterpret_cast<uint32_t*>(&r);
 #pragma unroll
-  for (int i = 0; i < NW; i++) d[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)s[i], CTRL, 0xF, 0xF, true);
+  for (int i = 0; i < NW; i++) {
+    d[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)s[i], CTRL, 0xF, 0xF, true);
+#if ZG_QUAD_DPP_STANDALONE
+    asm volatile("" : "+v"(d[i]));
+#endif
+  }
   return r;
+#else
+  const int lane = quad_host_lane();
+  return quad_host()->exchange(v, lane, (CTRL >> (2 * lane)) & 3);
+#endif
 }
 constexpr int quad_ctrl(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 constexpr int quad_bcast(int a) { return quad_ctrl(a, a, a, a); }
 
-__device__ __forceinline__ int quad_bcast_flag(bool f, int lane) {
+ZG_HD int quad_bcast_flag(bool f, int lane) {
   const int v = f ? 1 : 0;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return quad_host()->exchange(v, quad_host_lane(), lane);
+#else
   switch (lane) {
     case 0: return __builtin_amdgcn_mov_dpp(v, quad_bcast(0), 0xF, 0xF, true);
     case 1: return __builtin_amdgcn_mov_dpp(v, quad_bcast(1), 0xF, 0xF, true);
     case 2: return __builtin_amdgcn_mov_dpp(v, quad_bcast(2), 0xF, 0xF, true);
     default: return __builtin_amdgcn_mov_dpp(v, quad_bcast(3), 0xF, 0xF, true);
   }
+#endif
+}
+// true when the flag is set on any lane of the wave (host: of the quad): the condition of a branch that every quad must
+// take together because the code behind it exchanges data between lanes
+ZG_HD bool quad_wave_any(bool f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(f) != 0ull;
+#else
+  bool any = false;
+  for (int l = 0; l < 4; l++) any |= quad_host()->exchange((int)f, quad_host_lane(), l) != 0;
+  return any;
+#endif
 }
 
 template <class F>
-__device__ __forceinline__ F fsel(bool take_b, const F& a, const F& b) {
+ZG_HD F fsel(bool take_b, const F& a, const F& b) {
   constexpr int NW = sizeof(F) / 4;
   F r;
   const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
@@ -66,7 +142,7 @@ __device__ __forceinline__ F fsel(bool take_b, const F& a, const F& b) {
 
 // this lane's coordinate of 2 * (the quad's point); q = lane & 3
 template <class F>
-__device__ __forceinline__ F quad_dbl(const F& c, unsigned q) {
+ZG_HD F quad_dbl(const F& c, unsigned q) {
   const bool inf = quad_bcast_flag(c.is_zero(), 2) != 0;  // ZZ == 0
   const F U = F::dbl(c);                                  // meaningful on lane 1: 2 Y
   // round 1: lane 0 X X, lane 1 U U
@@ -92,7 +168,7 @@ __device__ __forceinline__ F quad_dbl(const F& c, unsigned q) {
 
 // this lane's coordinate of P1 + P2 (c1, c2: this lane's coordinates of the two points)
 template <class F>
-__device__ __forceinline__ F quad_add(const F& c1, const F& c2, unsigned q) {
+ZG_HD F quad_add(const F& c1, const F& c2, unsigned q) {
   const bool inf1 = quad_bcast_flag(c1.is_zero(), 2) != 0;
   const bool inf2 = quad_bcast_flag(c2.is_zero(), 2) != 0;
   // round 1: X1 ZZ2, ZZ1 X2, Y1 ZZZ2, ZZZ1 Y2
@@ -124,7 +200,7 @@ __device__ __forceinline__ F quad_add(const F& c1, const F& c2, unsigned q) {
   // exceptional cases
   if (p_zero && !inf1 && !inf2) {  // same x: the same point (double it) or opposite points (the identity)
     r = F::zero();
-    if (__builtin_amdgcn_ballot_w64(r_zero) != 0ull) {  // rare: entered by the wave, computed by every quad, kept where it applies
+    if (quad_wave_any(r_zero)) {  // rare: entered by the wave, computed by every quad, kept where it applies
       const F dd = quad_dbl(c1, q);
       if (r_zero) r = dd;
     }
@@ -136,11 +212,11 @@ __device__ __forceinline__ F quad_add(const F& c1, const F& c2, unsigned q) {
 
 // this lane's coordinate of a point in memory / store it
 template <class F>
-__device__ __forceinline__ F quad_load(const XYZZ<F>* p, unsigned q) {
+ZG_HD F quad_load(const XYZZ<F>* p, unsigned q) {
   return reinterpret_cast<const F*>(p)[q];
 }
 template <class F>
-__device__ __forceinline__ void quad_store(XYZZ<F>* p, unsigned q, const F& c) {
+ZG_HD void quad_store(XYZZ<F>* p, unsigned q, const F& c) {
   reinterpret_cast<F*>(p)[q] = c;
 }
 

@@ -29,6 +29,7 @@
 #include "accum29x2.cuh"
 #include "curve.cuh"
 #include "curve_quad.cuh"
+#include "curve_quad29.cuh"
 
 namespace zg {
 
@@ -771,6 +772,21 @@ struct Radix29For<Fp2<Fp<P>, NR>> {
   static constexpr bool value = ZG_ACCUM_RADIX29_G2 != 0;
 };
 
+// the arithmetic of the quad kernels (k_combine_*, k_reduce*) for coordinate field F, and with it the form of the
+// buffers they exchange with k_accum
+template <class F>
+struct QuadSel {
+  using type = QuadOps32<F>;
+};
+#if ZG_QUAD_RADIX29
+template <class P>
+struct QuadSel<Fp<P>> {
+  using type = std::conditional_t<Radix29For<Fp<P>>::value, QuadOps29<P>, QuadOps32<Fp<P>>>;
+};
+#endif
+template <class F>
+using QuadOps = typename QuadSel<F>::type;
+
 #ifndef ZG_ACCUM_TOUCH
 #define ZG_ACCUM_TOUCH 0
 #endif
@@ -836,7 +852,10 @@ __global__ void __launch_bounds__(ZG_ACCUM_BLOCK, ZG_ACCUM_MIN_WAVES) k_accum(co
       touch_prev = touch;
 #endif
     }
-    part[u] = A::to_xyzz(acc);
+    if constexpr (QuadOps<F>::rprime_buffers)
+      part[u] = A::to_part(acc);
+    else
+      part[u] = A::to_xyzz(acc);
   } else {
     p.y = F::cneg(p.y, (e >> 31) != 0);
     XYZZ<F> acc = XYZZ<F>::from_affine(p);
@@ -886,9 +905,10 @@ __global__ void __launch_bounds__(256) k_combine_light(const UnitDesc* __restric
   if (ufirst[b] != u) return;  // only a bucket's first unit
   const uint32_t nu = (cnt[b] + L - 1) / L;
   if (nu < 2 || nu > smax) return;
-  F a = quad_load(part + u, q);
-  for (uint32_t k = 1; k < nu; k++) a = quad_add(a, quad_load(part + u + k, q), q);
-  quad_store(part + u, q, a);
+  using Q = QuadOps<F>;
+  typename Q::Coord a = Q::load(part + u, q);
+  for (uint32_t k = 1; k < nu; k++) a = Q::add(a, Q::load(part + u + k, q), q);
+  Q::store(part + u, q, a);
 }
 
 // grid (chunk slots, heavy slots); elements of this level: part[first + stride * j], j < ceil(units / stride)
@@ -899,6 +919,7 @@ __global__ void __launch_bounds__(quad_block<F>()) k_combine_tree(const uint32_t
                                                                    const uint32_t* __restrict__ max_units /* most units in any bucket */) {
   // chunk slots beyond the longest bucket have nothing to do in any heavy bucket
   if ((size_t)blockIdx.x * COMBINE_CHUNK * stride >= max_units[0]) return;
+  using Q = QuadOps<F>;
   const uint32_t nheavy = heavy[0];
   const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
   for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
@@ -911,9 +932,9 @@ __global__ void __launch_bounds__(quad_block<F>()) k_combine_tree(const uint32_t
       const uint32_t c1 = c0 + COMBINE_CHUNK < nelem ? c0 + COMBINE_CHUNK : nelem;
       for (uint32_t s = 1; s < COMBINE_CHUNK && c0 + s < c1; s <<= 1) {
         for (uint32_t j0 = c0 + 2 * s * qi; j0 + s < c1; j0 += 2 * s * nq) {
-          const F a = quad_load(base + (size_t)stride * j0, q);
-          const F c = quad_load(base + (size_t)stride * (j0 + s), q);
-          quad_store(base + (size_t)stride * j0, q, quad_add(a, c, q));
+          const typename Q::Coord a = Q::load(base + (size_t)stride * j0, q);
+          const typename Q::Coord c = Q::load(base + (size_t)stride * (j0 + s), q);
+          Q::store(base + (size_t)stride * j0, q, Q::add(a, c, q));
         }
         __syncthreads();
       }
@@ -933,38 +954,51 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
   if (g >= T * W) return;
   const uint32_t w = g / T, j = g % T;
-  F run = F::zero(), tot = F::zero();  // the identity: every coordinate zero
+  using Q = QuadOps<F>;
+  using Coord = typename Q::Coord;
+  Coord run = Q::zero(), tot = Q::zero();  // the identity: every coordinate zero
   for (int bb = (int)k - 1; bb >= 0; bb--) {
     const size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
-    if (cnt[gid]) run = quad_add(run, quad_load(part + ufirst[gid], q), q);  // k_combine left the bucket sum in its first unit
-    tot = quad_add(tot, run, q);
+    if (cnt[gid]) run = Q::add(run, Q::load(part + ufirst[gid], q), q);  // k_combine left the bucket sum in its first unit
+    tot = Q::add(tot, run, q);
   }
   // tot = sum (b - j*k + 1) B_b ; add (j*k) * run, j*k < nb
   const uint32_t start = j * k;
-  F r = F::zero();
+  Coord r = Q::zero();
   for (int b = 31 - __builtin_clz(nb > 1 ? nb - 1 : 1); b >= 0; b--) {
-    r = quad_dbl(r, q);
-    if ((start >> b) & 1u) r = quad_add(r, run, q);
+    r = Q::dbl(r, q);
+    if ((start >> b) & 1u) r = Q::add(r, run, q);
   }
-  tot = quad_add(tot, r, q);
-  quad_store(seg + g, q, tot);
-  if (seg_plain) quad_store(seg_plain + g, q, run);
+  tot = Q::add(tot, r, q);
+  Q::store(seg + g, q, tot);
+  if (seg_plain) Q::store(seg_plain + g, q, run);
 }
 
 // one block per window: tree-sum seg[w*T .. w*T+T) into seg[w*T]
 template <class F>
 __global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
   XYZZ<F>* s = seg + (size_t)blockIdx.x * T;  // (table mode: the unweighted sums follow as gridDim.x / 2 more rows)
+  using Q = QuadOps<F>;
   const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
+  if (T == 1) {  // nothing to add: the row's one segment sum only changes form
+    if (qi == 0) Q::store_final(s, q, Q::load(s, q));
+    return;
+  }
   if (T > nq) {  // fold the tail onto the first nq entries
-    F a = quad_load(s + qi, q);
-    for (uint32_t j = qi + nq; j < T; j += nq) a = quad_add(a, quad_load(s + j, q), q);
-    quad_store(s + qi, q, a);
+    typename Q::Coord a = Q::load(s + qi, q);
+    for (uint32_t j = qi + nq; j < T; j += nq) a = Q::add(a, Q::load(s + j, q), q);
+    Q::store(s + qi, q, a);
     __syncthreads();
     T = nq;
   }
   for (uint32_t h = T >> 1; h >= 1; h >>= 1) {
-    if (qi < h) quad_store(s + qi, q, quad_add(quad_load(s + qi, q), quad_load(s + qi + h, q), q));
+    if (qi < h) {
+      const typename Q::Coord r = Q::add(Q::load(s + qi, q), Q::load(s + qi + h, q), q);
+      if (h == 1)
+        Q::store_final(s, q, r);  // the row's sum, read by the host: the library's stored form
+      else
+        Q::store(s + qi, q, r);
+    }
     __syncthreads();
   }
 }
