@@ -104,6 +104,8 @@ def measure(args, ctx=None):
         times.append(time.perf_counter() - t)
     raw = out.raw
     proof = (zl.decode_point(cid, 1, raw[: 2 * n]), zl.decode_point(cid, 2, raw[2 * n: 6 * n]), zl.decode_point(cid, 1, raw[6 * n:]))
+    if os.environ.get("ZG_BENCH_PROVE_SAMPLES"):
+        print("samples_ms", " ".join("%.2f" % (x * 1e3) for x in times), file=sys.stderr)
     times.sort()
     # Throughput with K proofs in flight (BASELINE configs[4], one device's share): K host threads, each with a
     # clone of the resident key (shared bases, own scratch and streams), every proof checked against the serial one.

@@ -391,7 +391,15 @@ struct ProvingKeyDev : PkBase {
     // the main stream's kernels: a proof did not finish in 100 s)
     static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
     static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
-    auto width = [](uint32_t dense) { return lane_c ? lane_c : dense ? msm_pick_c(dense < 256 ? 256 : dense) : 0; };
+    // One bit narrower than a lone evaluation of that size would take (msm_pick_c): with five evaluations sharing the
+    // device the reduction's chains count for more (JoinSplit shape, 44 K dense scalars: width 12 against 13 is 0.15-0.2 ms
+    // of a proof; 11 and 14 are slower than either)
+    auto width = [](uint32_t dense) {
+      if (lane_c) return lane_c;
+      if (!dense) return 0;
+      const int c = msm_pick_c(dense < 256 ? 256 : dense);
+      return c == 13 ? 12 : c;
+    };
     // A proof is ~100 kernel launches and the host needs 20-35 us for each: queued from one thread, the last lane's
     // first kernel started 3.3 ms after the proof began (rocprofv3 timeline, JoinSplit scale) although its input was
     // ready after 0.05 ms.  Every lane is therefore queued by a thread of its own while this thread queues the H chain.
@@ -410,6 +418,10 @@ struct ProvingKeyDev : PkBase {
     };
     static const bool serial_queue = getenv("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
     std::thread workers[4];
+    // the head of the longest chain is queued before the lanes' threads are started (their creation is ~0.1 ms of this
+    // thread's time, during which the device would have nothing of the H chain to run)
+    const bool head_first = h_status == ZG_OK && hold == 0;
+    if (head_first) h_status = qap_h(0, 0);
     if (!serial_queue) {
       for (int i = 0; i < 4; i++) {
         try {
@@ -419,7 +431,7 @@ struct ProvingKeyDev : PkBase {
         }
       }
     }
-    if (h_status == ZG_OK && !(hold >= 3)) h_status = qap_h(hold >= 1 && hold <= 3 ? hold : 0, 2);
+    if (h_status == ZG_OK && !(hold >= 3)) h_status = qap_h(hold >= 1 && hold <= 3 ? hold : (head_first ? 1 : 0), 2);
     const MsmTable h_tab{H_len, 0, H_c, H_levels};
     if (h_status == ZG_OK) h_status = o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr);
     for (int i = 0; i < 4; i++) {
