@@ -34,7 +34,7 @@ elif [ "$1" = "2" ]; then
     timeout -k 10 100 python bench.py --no-table --no-prove --no-cpu-baseline > "$O/bench_windowed.json" 2>> "$O/sweep.err" &&
     timeout -k 10 200 python tools/bench_sweep.py other > "$O/msm_g2_bls.jsonl" 2>> "$O/sweep.err" &&
     timeout -k 10 100 python tools/bench_sweep.py ntt > "$O/ntt.jsonl" 2>> "$O/sweep.err" &&
-    timeout -k 10 200 python tools/bench_prove.py --in-flight 4 > "$O/prove_joinsplit_shaped.json" 2> "$O/prove.err" &&
+    timeout -k 10 200 python tools/bench_prove.py --in-flight 4 --steps 40 > "$O/prove_joinsplit_shaped.json" 2> "$O/prove.err" &&
     cat "$O/prove_joinsplit_shaped.json" &&
     cd /tmp &&
     timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d "$O/prof_prove" -o prove -- python3 "$R/tools/bench_prove.py" --no-cpu --in-flight 0 > "$O/prof_prove.log" 2>&1 &&

@@ -13,3 +13,5 @@ cp $O/prove_bls377_2p22.json profiles/${R}_prove_bls377_2p22.json
 python3 tools/prof_summary.py $O/prof_prove/prove_results.db 12 > profiles/${R}_prove_kernel_stats.txt
 python3 tools/prof_timeline.py $O/prof_prove/prove_results.db > profiles/${R}_prove_timeline.txt
 python3 tools/prof_overlap.py $O/prof_prove_if4/if4_results.db 0.84 0.98 > profiles/${R}_prove_overlap_4_in_flight.txt
+{ echo "# rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace -- python3 tools/bench_prove.py --no-cpu --no-verify --in-flight 0 --steps 2"; echo "# (alt-bn128 JoinSplit-shaped proof, 2^19 domain; one proof of the run; tools/pmc_valu_by_kernel.py)"; python3 tools/pmc_valu_by_kernel.py $O/pmc_prove; } > profiles/${R}_prove_valu_by_kernel.txt
+python3 tools/prof_proofs.py $O/prof_prove/prove_results.db > profiles/${R}_prove_per_proof.txt
