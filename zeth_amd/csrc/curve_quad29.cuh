@@ -24,6 +24,12 @@ namespace zg {
 #define ZG_QUAD_RADIX29 1
 #endif
 
+// the product of these kernels: 0 the instruction form (one chain per column: best at two or more waves per SIMD),
+// 1 plain C (the compiler splits a column as it sees fit), 2 plain C with the reduction's products on a chain of their own
+#ifndef ZG_QUAD29_MUL
+#define ZG_QUAD29_MUL 0
+#endif
+
 template <class P>
 struct Quad29 {
   using K = K29<P>;
@@ -31,6 +37,24 @@ struct Quad29 {
   using N2 = E29<P, 2, LN>;
   using C = E29<P, 10, LN + 15>;
 
+  template <class A, class Bt>
+  ZG_HD static N2 mul(const A& a, const Bt& b) {
+#if ZG_QUAD29_MUL == 1
+    return f29::mul_chains(a, b);
+#elif ZG_QUAD29_MUL == 2
+    return f29::mul_chains2(a, b);
+#else
+    return f29::mul(a, b);
+#endif
+  }
+  template <class A>
+  ZG_HD static N2 sqr(const A& a) {
+#if ZG_QUAD29_MUL == 0
+    return f29::sqr(a);
+#else
+    return mul(a, a);
+#endif
+  }
   template <class E>
   ZG_HD static C can(const E& e) {
     return f29::widen<C::vb, C::lmax>(e);
@@ -63,7 +87,7 @@ struct Quad29 {
   ZG_HD static C dbl(const C& c, unsigned q) {
     const bool inf = quad_bcast_flag(zz_zero(c), 2) != 0;
     // round 1: lane 0 X^2, lane 1 Y^2
-    const N2 m1 = f29::sqr(c);
+    const N2 m1 = sqr(c);
     const N2 YY = quad_perm<quad_bcast(1)>(m1), XX = quad_perm<quad_bcast(0)>(m1);
     const auto V = f29::carry(f29::dbl(f29::dbl(YY)));         // U^2, U = 2 Y
     const auto M = f29::carry(f29::add(f29::dbl(XX), XX));     // 3 X^2
@@ -71,13 +95,13 @@ struct Quad29 {
     // round 2: X V, U V, ZZ V, M M
     const auto a2 = sel(q == 3, sel(q == 1, c, U), M);
     const auto b2 = sel(q == 3, V, M);
-    const N2 m2 = f29::mul(a2, b2);  // S, W, ZZ3, MM
+    const N2 m2 = mul(a2, b2);  // S, W, ZZ3, MM
     // round 3: -, M (S - X3), W Y, W ZZZ
     const N2 S = quad_perm<quad_bcast(0)>(m2), W = quad_perm<quad_bcast(1)>(m2);
     const auto X3 = f29::carry(f29::sub(quad_perm<quad_bcast(3)>(m2), f29::dbl(S)));
     const auto a3 = sel(q == 1, W, M);
     const auto b3 = sel(q == 3, sel(q == 1, quad_perm<quad_bcast(1)>(c), f29::carry(f29::sub(S, X3))), c);
-    const N2 m3 = f29::mul(a3, b3);  // -, t, u, ZZZ3
+    const N2 m3 = mul(a3, b3);  // -, t, u, ZZZ3
     const auto Y3 = f29::carry(f29::sub(m3, quad_perm<quad_bcast(2)>(m3)));
     const C r = can(sel(q == 3, sel(q == 2, sel(q == 1, X3, Y3), m2), m3));
     return f29::select(r, c, inf);
@@ -88,31 +112,31 @@ struct Quad29 {
     const bool inf1 = quad_bcast_flag(zz_zero(c1), 2) != 0;
     const bool inf2 = quad_bcast_flag(zz_zero(c2), 2) != 0;
     // round 1: X1 ZZ2, ZZ1 X2, Y1 ZZZ2, ZZZ1 Y2
-    const N2 m1 = f29::mul(quad_perm<quad_ctrl(0, 2, 1, 3)>(c1), quad_perm<quad_ctrl(2, 0, 3, 1)>(c2));  // U1, U2, S1, S2
+    const N2 m1 = mul(quad_perm<quad_ctrl(0, 2, 1, 3)>(c1), quad_perm<quad_ctrl(2, 0, 3, 1)>(c2));  // U1, U2, S1, S2
     // P on lanes 0, 1; R on lanes 2, 3
     const auto d = f29::carry(f29::sub(quad_perm<quad_ctrl(1, 1, 3, 3)>(m1), quad_perm<quad_ctrl(0, 0, 2, 2)>(m1)));
     // round 2: P P, ZZ1 ZZ2, R R, ZZZ1 ZZZ2
     const bool odd = (q & 1u) != 0;
     const auto a2 = sel(odd, d, quad_perm<quad_ctrl(0, 2, 0, 3)>(c1));
     const auto b2 = sel(odd, d, quad_perm<quad_ctrl(0, 2, 0, 3)>(c2));
-    const N2 m2 = f29::mul(a2, b2);  // PP, ZZ12, RR, ZZZ12
+    const N2 m2 = mul(a2, b2);  // PP, ZZ12, RR, ZZZ12
     // round 3: PP times P, U1, ZZ12
     const N2 PP = quad_perm<quad_bcast(0)>(m2);
     const auto o3 = sel(q >= 2, sel(q == 1, d, quad_perm<quad_bcast(0)>(m1)), quad_perm<quad_bcast(1)>(m2));
-    const N2 m3 = f29::mul(PP, o3);  // PPP, Q, ZZ3, (unused)
+    const N2 m3 = mul(PP, o3);  // PPP, Q, ZZ3, (unused)
     // round 4: -, R (Q - X3), S1 PPP, ZZZ12 PPP
     const N2 PPP = quad_perm<quad_bcast(0)>(m3), Q = quad_perm<quad_bcast(1)>(m3);
     const auto X3 = f29::carry(f29::sub(quad_perm<quad_bcast(2)>(m2), f29::add(PPP, f29::dbl(Q))));
     const auto a4 = sel(q >= 2, quad_perm<quad_bcast(2)>(d), sel(q == 3, m1, m2));
     const auto b4 = sel(q >= 2, f29::carry(f29::sub(Q, X3)), PPP);
-    const N2 m4 = f29::mul(a4, b4);  // -, t, u, ZZZ3
+    const N2 m4 = mul(a4, b4);  // -, t, u, ZZZ3
     const auto Y3 = f29::carry(f29::sub(m4, quad_perm<quad_bcast(2)>(m4)));
     C r = can(sel(q == 3, sel(q == 2, sel(q == 1, X3, Y3), m3), m4));
     // exceptional cases.  ZZ3 = ZZ1 ZZ2 P^2 is congruent to zero exactly when an input is the identity or P is: with both
     // inputs finite the points share their x -- the same point (R = 0: double it) or opposite points (the identity)
     const bool same_x = quad_bcast_flag(f29::is_zero_mod_p(m3), 2) != 0 && !inf1 && !inf2;
     if (quad_wave_any(same_x)) {  // rare: entered by the wave, computed by every quad, kept where it applies
-      const bool r_zero = quad_bcast_flag(f29::is_zero_mod_p(f29::mul(d, f29::one<P>())), 2) != 0;
+      const bool r_zero = quad_bcast_flag(f29::is_zero_mod_p(mul(d, f29::one<P>())), 2) != 0;
       const C dd = dbl(c1, q);
       r = f29::select(r, f29::select(zero(), dd, r_zero), same_x);
     }

@@ -472,6 +472,16 @@ ZG_HD E29<P, 2, K29<P>::LNORM> mul_chains(const E29<P, VA, LA>& a, const E29<P, 
   return mont_columns<P, 1>([&](uint64_t* chain, int i, int j) { mac_c(chain[0], a.v[i], b.v[j]); });
 }
 
+// a b with the limb products on one chain and the m_i p_j products on another: two independent chains per column for the
+// latency-bound quad kernels (curve_quad29.cuh), which run at one or two waves per SIMD
+template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB>
+ZG_HD E29<P, 2, K29<P>::LNORM> mul_chains2(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b) {
+  using K = K29<P>;
+  static_assert(K::column_fits(VA, LA, VB, LB), "mul: a column overflows 64 bits -- carry() an operand first");
+  static_assert(VA * VB <= K::mont_room(), "mul: operands too large for a result below 2 p");
+  return mont_columns<P, 2>([&](uint64_t* chain, int i, int j) { mac_c(chain[0], a.v[i], b.v[j]); });
+}
+
 // a b + c d with a chain per product (mul_add above keeps one: best with two or more waves on a SIMD)
 template <class P, uint64_t VA, uint64_t LA, uint64_t VB, uint64_t LB, uint64_t VC, uint64_t LC, uint64_t VD, uint64_t LD>
 ZG_HD E29<P, 2, K29<P>::LNORM> mul_add_chains(const E29<P, VA, LA>& a, const E29<P, VB, LB>& b, const E29<P, VC, LC>& c,
