@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <utility>
 #include <vector>
 
 #include "accum29.cuh"
@@ -84,7 +85,7 @@ inline int ilog2_floor(size_t n) {
 }
 
 // The multiples 2^(j c) P_i, j < D, of a fixed-base table: D for a scalar field of `scalar_bits` bits
-inline int msm_table_digits(int scalar_bits, int c) { return (scalar_bits + 2 + c - 1) / c; }
+constexpr int msm_table_digits(int scalar_bits, int c) { return (scalar_bits + 2 + c - 1) / c; }
 static constexpr int MSM_TABLE_MIN_C = 10, MSM_TABLE_MAX_C = 22;
 
 // Digit width of the table for N fixed bases, measured on MI355X (BN254 G1, tools/bench_sweep.py g1t): 22 from 2^23
@@ -251,6 +252,40 @@ __device__ __forceinline__ void recode_scalar(const uint32_t* __restrict__ scala
       have -= c;
       w++;
     }
+  }
+}
+
+// The same digits for a digit width known at compile time: every digit sits at a fixed bit offset, so all of them stay in
+// registers (dg[j], j < D) and the caller makes ONE pass over them
+template <class Fr, int C, int D>
+__device__ __forceinline__ void recode_scalar_static(const uint32_t* __restrict__ scalars, size_t i, int mont, const AddConst& K,
+                                                     bool* dense, int (&dg)[D]) {
+  Fr s;
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  uint4 lo = sp[0], hi = sp[1];
+  s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+  s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+  if (mont) s = Fr::from_mont(s);
+  uint32_t hi_bits = s.v[0] >> 1;
+#pragma unroll
+  for (int j = 1; j < 8; j++) hi_bits |= s.v[j];
+  *dense = hi_bits != 0;
+  uint32_t t[9];
+  uint64_t cy = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    cy += (uint64_t)s.v[j] + K.k[j];
+    t[j] = (uint32_t)cy;
+    cy >>= 32;
+  }
+  t[8] = (uint32_t)cy + K.k[8];
+  static_assert(C * D <= 288 && C <= 32, "digits outside the 288-bit sum");
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    const int bit = j * C, q = bit >> 5, sh = bit & 31;  // constants once the loop is unrolled
+    const uint32_t lo = t[q], hi = q + 1 < 9 ? t[q + 1] : 0u;
+    const uint32_t w = sh ? (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) : lo;
+    dg[j] = (int)(w & (uint32_t)((1ull << C) - 1ull)) - (1 << (C - 1));
   }
 }
 

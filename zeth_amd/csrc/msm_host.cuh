@@ -262,9 +262,16 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     hipLaunchKernelGGL((k_table_count<Fr>), dim3((unsigned)cblocks), dim3(256), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K,
                        (uint32_t)p.W - 1u, gcnt, dense_counters);
     hipLaunchKernelGGL(k_table_starts, dim3(1), dim3(64), 0, st, gcnt, (uint32_t)p.W, gstart, gcursor);
-    hipLaunchKernelGGL((k_table_scatter<Fr>), dim3((unsigned)((n + tile_scalars - 1) / tile_scalars)), dim3(1024), 0, st, d_scalars,
-                       n, scalars_mont, p.c, p.D, p.K, p.gbits, (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first,
-                       gcursor, fent, fkey);
+    const dim3 sgrid((unsigned)((n + tile_scalars - 1) / tile_scalars));
+    if (p.c == 22 && p.D == msm_table_digits(Fr::Params::BITS, 22))
+      hipLaunchKernelGGL((k_table_scatter_static<Fr, 22>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+    else if (p.c == 20 && p.D == msm_table_digits(Fr::Params::BITS, 20))
+      hipLaunchKernelGGL((k_table_scatter_static<Fr, 20>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+    else
+      hipLaunchKernelGGL((k_table_scatter<Fr>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K, p.gbits,
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
     ctx->mark("hist");
     hipLaunchKernelGGL(k_hist_table, dim3(p.nchunk, p.W), dim3(1024), lds, st, fkey, gstart, p.nb, cnt);
   } else {

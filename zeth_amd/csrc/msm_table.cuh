@@ -109,6 +109,68 @@ __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restri
   }
 }
 
+// The same for a digit width known at compile time (the widths msm_table_pick_c chooses): the scalar is recoded ONCE, its
+// digits and their ranks within their groups stay in registers, and every entry costs one LDS atomic instead of two
+// (2^24 points, c = 22: 0.77 -> see DESIGN 4.2).
+template <class Fr, int C>
+__global__ void __launch_bounds__(1024) k_table_scatter_static(const uint32_t* __restrict__ scalars, size_t n, int mont, AddConst K,
+                                                                int gbits, uint32_t W, uint32_t tile_scalars, uint32_t table_n,
+                                                                uint32_t first, uint32_t* __restrict__ gcursor,
+                                                                uint32_t* __restrict__ fent, uint16_t* __restrict__ fkey) {
+  constexpr int D = msm_table_digits(Fr::Params::BITS, C);
+  __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
+  __shared__ uint32_t buf_ent[TABLE_TILE];
+  __shared__ uint16_t buf_key[TABLE_TILE];
+  __shared__ uint8_t buf_bin[TABLE_TILE];
+  const size_t i = (size_t)blockIdx.x * tile_scalars + threadIdx.x;
+  const bool live = threadIdx.x < tile_scalars && i < n;
+  const uint32_t gmask = W - 1u;
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
+  __syncthreads();
+  int dg[D];
+  uint32_t rk[D];
+  if (live) {
+    bool dense;
+    recode_scalar_static<Fr, C, D>(scalars, i, mont, K, &dense, dg);
+#pragma unroll
+    for (int j = 0; j < D; j++)
+      if (dg[j] != 0) rk[j] = atomicAdd(&h[(uint32_t)((dg[j] < 0 ? -dg[j] : dg[j]) - 1) & gmask], 1u);
+  }
+  __syncthreads();
+  uint32_t v = 0, incl = 0;
+  if (threadIdx.x < 128) {
+    v = threadIdx.x < W ? h[threadIdx.x] : 0;
+    incl = wave_inclusive_scan(v);
+    if (threadIdx.x == 63) wsum = incl;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
+    lstart[threadIdx.x] = excl;
+    gbase[threadIdx.x] = v ? atomicAdd(&gcursor[threadIdx.x], v) : 0;
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < D; j++)
+      if (dg[j] != 0) {
+        const uint32_t b = (uint32_t)((dg[j] < 0 ? -dg[j] : dg[j]) - 1);
+        const uint32_t pos = lstart[b & gmask] + rk[j];
+        buf_ent[pos] = ((uint32_t)j * table_n + first + (uint32_t)i) | (dg[j] < 0 ? 0x80000000u : 0u);
+        buf_key[pos] = (uint16_t)(b >> gbits);
+        buf_bin[pos] = (uint8_t)(b & gmask);
+      }
+  }
+  __syncthreads();
+  const uint32_t total = lstart[W - 1] + h[W - 1];
+  for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+    const uint32_t bin = buf_bin[q];
+    const uint32_t g = gbase[bin] + (q - lstart[bin]);
+    fent[g] = buf_ent[q];
+    fkey[g] = buf_key[q];
+  }
+}
+
 // bucket counts of a group from its key list (k_hist's counterpart); grid (chunks, W)
 static __global__ void __launch_bounds__(1024) k_hist_table(const uint16_t* __restrict__ fkey, const uint32_t* __restrict__ gstart,
                                                             uint32_t nb, uint32_t* __restrict__ cnt) {
