@@ -517,10 +517,15 @@ static __global__ void __launch_bounds__(1024) k_scatter(const int16_t* __restri
 #ifndef ZG_SORT_WG
 #define ZG_SORT_WG 1024
 #endif
-static constexpr uint32_t SORT_WG = ZG_SORT_WG;      // lanes of k_scatter_hi_table and k_scatter_lo, eight entries each
-static constexpr uint32_t SORT_TILE1 = 8192;         // k_scatter_hi (1024 lanes)
-static constexpr uint32_t SORT_TILE1T = 8 * SORT_WG; // k_scatter_hi_table
-static constexpr uint32_t SORT_TILE2 = 8 * SORT_WG;  // k_scatter_lo
+#ifndef ZG_SORT_PER
+#define ZG_SORT_PER 8
+#endif
+static constexpr uint32_t SORT_WG = ZG_SORT_WG;      // lanes of k_scatter_hi_table and k_scatter_lo
+static constexpr uint32_t SORT_PER = ZG_SORT_PER;    // consecutive entries per lane (a multiple of eight)
+static_assert(SORT_PER % 8 == 0 && (SORT_PER & (SORT_PER - 1)) == 0, "entries are read eight at a time; tiles start on multiples of SORT_PER");
+static constexpr uint32_t SORT_TILE1 = 8192;                // k_scatter_hi (1024 lanes)
+static constexpr uint32_t SORT_TILE1T = SORT_PER * SORT_WG; // k_scatter_hi_table
+static constexpr uint32_t SORT_TILE2 = SORT_PER * SORT_WG;  // k_scatter_lo
 
 // Both levels sort their tile inside LDS first (histogram, exclusive scan, ranked placement) and then copy the LDS
 // image out linearly, so that a wave writes 64 consecutive entries of (mostly) one run: full-line global stores.
@@ -599,27 +604,29 @@ static __global__ void __launch_bounds__(SORT_WG) k_scatter_lo(const uint32_t* _
   const uint32_t p = blockIdx.y, w = w0 + blockIdx.z;
   const uint32_t start = pstart[(size_t)w * (nhi + 1) + p], end = pstart[(size_t)w * (nhi + 1) + p + 1];
   uint32_t* cur = cursor + (size_t)w * nb + (size_t)p * 256;
-  // tiles on multiples of eight entries, eight consecutive entries per lane (see k_scatter_hi_table)
-  for (uint32_t lo = (start & ~7u) + blockIdx.x * SORT_TILE2; lo < end; lo += gridDim.x * SORT_TILE2) {
+  // tiles on multiples of SORT_PER entries, consecutive entries per lane read eight at a time (see k_scatter_hi_table)
+  for (uint32_t lo = (start & ~(SORT_PER - 1u)) + blockIdx.x * SORT_TILE2; lo < end; lo += gridDim.x * SORT_TILE2) {
     uint32_t hi = lo + SORT_TILE2;
     if (hi > end) hi = end;
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
-    // one pass over the tile: every lane keeps its (up to) 8 entries and their ranks within their bins in registers, so
-    // each entry costs one LDS atomic and one read of the intermediate arrays
-    constexpr uint32_t PER = SORT_TILE2 / SORT_WG;
-    static_assert(PER == 8, "eight entries per lane: one uint2 of bins, two uint4 of entries");
+    // one pass over the tile: every lane keeps its entries and their ranks within their bins in registers, so each
+    // entry costs one LDS atomic and one read of the intermediate arrays
+    constexpr uint32_t PER = SORT_PER;
     uint32_t my_ent[PER], my_rank[PER];
     uint32_t my_bin[PER];
     const uint32_t q0 = lo + threadIdx.x * PER;
-    if (q0 < hi) {  // reads up to seven entries past `end`: inside the workspace
-      const uint2 b = *reinterpret_cast<const uint2*>(mid_lo + q0);
-      const uint4 e0 = *reinterpret_cast<const uint4*>(mid_ent + q0);
-      const uint4 e1 = *reinterpret_cast<const uint4*>(mid_ent + q0 + 4);
-      my_bin[0] = b.x & 255u, my_bin[1] = (b.x >> 8) & 255u, my_bin[2] = (b.x >> 16) & 255u, my_bin[3] = b.x >> 24;
-      my_bin[4] = b.y & 255u, my_bin[5] = (b.y >> 8) & 255u, my_bin[6] = (b.y >> 16) & 255u, my_bin[7] = b.y >> 24;
-      my_ent[0] = e0.x, my_ent[1] = e0.y, my_ent[2] = e0.z, my_ent[3] = e0.w;
-      my_ent[4] = e1.x, my_ent[5] = e1.y, my_ent[6] = e1.z, my_ent[7] = e1.w;
+#pragma unroll
+    for (uint32_t c = 0; c < PER; c += 8) {
+      if (q0 + c < hi) {  // reads up to seven entries past `end`: inside the workspace
+        const uint2 b = *reinterpret_cast<const uint2*>(mid_lo + q0 + c);
+        const uint4 e0 = *reinterpret_cast<const uint4*>(mid_ent + q0 + c);
+        const uint4 e1 = *reinterpret_cast<const uint4*>(mid_ent + q0 + c + 4);
+        my_bin[c + 0] = b.x & 255u, my_bin[c + 1] = (b.x >> 8) & 255u, my_bin[c + 2] = (b.x >> 16) & 255u, my_bin[c + 3] = b.x >> 24;
+        my_bin[c + 4] = b.y & 255u, my_bin[c + 5] = (b.y >> 8) & 255u, my_bin[c + 6] = (b.y >> 16) & 255u, my_bin[c + 7] = b.y >> 24;
+        my_ent[c + 0] = e0.x, my_ent[c + 1] = e0.y, my_ent[c + 2] = e0.z, my_ent[c + 3] = e0.w;
+        my_ent[c + 4] = e1.x, my_ent[c + 5] = e1.y, my_ent[c + 6] = e1.z, my_ent[c + 7] = e1.w;
+      }
     }
 #pragma unroll
     for (uint32_t r = 0; r < PER; r++) {

@@ -251,26 +251,28 @@ static __global__ void __launch_bounds__(SORT_WG) k_scatter_hi_table(const uint3
   __shared__ uint8_t buf_lo[SORT_TILE1T], buf_bin[SORT_TILE1T];
   const uint32_t w = blockIdx.y;
   const uint32_t start = gstart[w], end = gstart[w + 1];
-  // Tiles start on multiples of eight entries (the first one below `start`, its leading entries masked), so that a lane
-  // takes eight consecutive entries with one 16-byte load of keys and two of entries: with one narrow load per entry the
+  // Tiles start on multiples of SORT_PER entries (the first one below `start`, its leading entries masked), so that a lane
+  // takes consecutive entries, eight at a time with one 16-byte load of keys and two of entries: with one narrow load per entry the
   // kernel waited on load latency, not bandwidth.  Which lane ranks which entry does not matter to a counting sort.
-  for (uint32_t lo = (start & ~7u) + blockIdx.x * SORT_TILE1T; lo < end; lo += gridDim.x * SORT_TILE1T) {
+  for (uint32_t lo = (start & ~(SORT_PER - 1u)) + blockIdx.x * SORT_TILE1T; lo < end; lo += gridDim.x * SORT_TILE1T) {
     const uint32_t hi = lo + SORT_TILE1T < end ? lo + SORT_TILE1T : end;
     if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
     // one pass: entries, keys and ranks within their bins stay in registers (one LDS atomic per entry)
-    constexpr uint32_t PER = SORT_TILE1T / SORT_WG;
-    static_assert(PER == 8, "eight entries per lane: one uint4 of keys, two of entries");
+    constexpr uint32_t PER = SORT_PER;
     uint32_t my_ent[PER], my_key[PER], my_rank[PER];
     const uint32_t q0 = lo + threadIdx.x * PER;
-    if (q0 < hi) {  // reads up to seven entries past `end`: inside the workspace (every array is followed by another)
-      const uint4 k = *reinterpret_cast<const uint4*>(fkey + q0);
-      const uint4 e0 = *reinterpret_cast<const uint4*>(fent + q0);
-      const uint4 e1 = *reinterpret_cast<const uint4*>(fent + q0 + 4);
-      my_key[0] = k.x & 0xFFFFu, my_key[1] = k.x >> 16, my_key[2] = k.y & 0xFFFFu, my_key[3] = k.y >> 16;
-      my_key[4] = k.z & 0xFFFFu, my_key[5] = k.z >> 16, my_key[6] = k.w & 0xFFFFu, my_key[7] = k.w >> 16;
-      my_ent[0] = e0.x, my_ent[1] = e0.y, my_ent[2] = e0.z, my_ent[3] = e0.w;
-      my_ent[4] = e1.x, my_ent[5] = e1.y, my_ent[6] = e1.z, my_ent[7] = e1.w;
+#pragma unroll
+    for (uint32_t c = 0; c < PER; c += 8) {
+      if (q0 + c < hi) {  // reads up to seven entries past `end`: inside the workspace (every array is followed by another)
+        const uint4 k = *reinterpret_cast<const uint4*>(fkey + q0 + c);
+        const uint4 e0 = *reinterpret_cast<const uint4*>(fent + q0 + c);
+        const uint4 e1 = *reinterpret_cast<const uint4*>(fent + q0 + c + 4);
+        my_key[c + 0] = k.x & 0xFFFFu, my_key[c + 1] = k.x >> 16, my_key[c + 2] = k.y & 0xFFFFu, my_key[c + 3] = k.y >> 16;
+        my_key[c + 4] = k.z & 0xFFFFu, my_key[c + 5] = k.z >> 16, my_key[c + 6] = k.w & 0xFFFFu, my_key[c + 7] = k.w >> 16;
+        my_ent[c + 0] = e0.x, my_ent[c + 1] = e0.y, my_ent[c + 2] = e0.z, my_ent[c + 3] = e0.w;
+        my_ent[c + 4] = e1.x, my_ent[c + 5] = e1.y, my_ent[c + 6] = e1.z, my_ent[c + 7] = e1.w;
+      }
     }
 #pragma unroll
     for (uint32_t r = 0; r < PER; r++) {
