@@ -328,7 +328,7 @@ def main():
         import bench_prove
 
         bases.free()
-        pargs = types.SimpleNamespace(curve="alt-bn128", scale=1.0, steps=10, warmup=2, constraints=0, in_flight=4,
+        pargs = types.SimpleNamespace(curve="alt-bn128", scale=1.0, steps=40, warmup=2, constraints=0, in_flight=4,
                                       no_cpu=(rank != 0 or args.no_cpu_baseline), no_verify=(rank != 0))
         prove = bench_prove.measure(pargs, ctx)
         # node throughput = proofs kept in flight on every device (BASELINE configs[4]); latency is reported beside it
