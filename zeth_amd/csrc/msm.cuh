@@ -373,13 +373,16 @@ static __global__ void __launch_bounds__(1024) k_hist(const int16_t* __restrict_
 }
 
 // inclusive prefix sum across the 64 lanes of a wave
+// (DPP moves: shifts inside the rows of 16 lanes, then the last lane of a row broadcast to the next row(s); through
+// __shfl_up each of the six steps was a trip through the LDS crossbar, and k_scan runs ~100 of these scans in a row)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
-  const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-  for (uint32_t d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(x, d);
-    if (lane >= d) x += t;
-  }
+  // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes with no source (or outside row_mask) get `old` = 0
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
   return x;
 }
 
@@ -406,10 +409,21 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
   const uint32_t* __restrict__ c = cnt + (size_t)w * nb;
   for (uint32_t q = tid; q <= UNIT_CLASSES; q += blockDim.x) lh[q] = 0;
   __syncthreads();
+  // the wave's counts, read once with all loads in flight together (a load per loop iteration in each of the two passes
+  // below was 64 dependent round trips to L2: most of this kernel's 65 us)
+  constexpr uint32_t MAXV = 32;  // nb <= 2^15 buckets over 16 waves of 64 lanes
+  uint32_t vals[MAXV];
+#pragma unroll
+  for (uint32_t i = 0; i < MAXV; i++) {
+    const uint32_t b = lo + i * 64 + lane;
+    vals[i] = b < hi ? c[b] : 0u;
+  }
   // pass 1: per-wave totals, histogram of unit length classes (v / L full units and one partial unit of v % L)
   uint32_t sa = 0, sb = 0, sc = 0, mx = 0;
-  for (uint32_t b = lo + lane; b < hi; b += 64) {
-    const uint32_t v = c[b];
+#pragma unroll
+  for (uint32_t i = 0; i < MAXV; i++) {
+    if (lo + i * 64 >= hi) break;  // wave-uniform
+    const uint32_t v = vals[i];
     const uint32_t nu = (v + L - 1) / L, fu = v / L;
     sa += v;
     sb += nu;
@@ -452,9 +466,12 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
   }
   const uint32_t abase = gstart ? gstart[w] : (uint32_t)((size_t)w * n);
   const uint32_t ubase = w * cap;
-  for (uint32_t b0 = lo; b0 < hi; b0 += 64) {
+#pragma unroll
+  for (uint32_t i = 0; i < MAXV; i++) {
+    const uint32_t b0 = lo + i * 64;
+    if (b0 >= hi) break;  // wave-uniform
     const uint32_t b = b0 + lane;
-    const uint32_t v = b < hi ? c[b] : 0;
+    const uint32_t v = vals[i];
     const uint32_t nu = (v + L - 1) / L, fu = v / L;
     const uint32_t ia = wave_inclusive_scan(v), ib = wave_inclusive_scan(nu), ic = wave_inclusive_scan(fu);
     if (b < hi) {
