@@ -360,10 +360,31 @@ static __global__ void __launch_bounds__(1024) k_hist(const int16_t* __restrict_
   size_t per = (n + nchunk - 1) / nchunk;
   size_t lo = (size_t)chunk * per, hi = lo + per;
   if (hi > n) hi = n;
-  const int16_t* d = dig + (size_t)w * n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int v = d[i];
+  // the bulk eight digits (16 bytes) per lane and load, two loads in flight; the unaligned ends one digit per lane (with
+  // one 2-byte load per lane the kernel waited on load latency: k_hist_table, msm_table.cuh)
+  auto count1 = [&](int v) {
     if (v != 0) atomicAdd(&lh[(v < 0 ? -v : v) - 1], 1u);
+  };
+  auto count8 = [&](const uint4& k) {
+    count1((int16_t)(k.x & 0xFFFFu)), count1((int16_t)(k.x >> 16)), count1((int16_t)(k.y & 0xFFFFu)), count1((int16_t)(k.y >> 16));
+    count1((int16_t)(k.z & 0xFFFFu)), count1((int16_t)(k.z >> 16)), count1((int16_t)(k.w & 0xFFFFu)), count1((int16_t)(k.w >> 16));
+  };
+  const size_t glo = (size_t)w * n + lo, ghi = (size_t)w * n + hi;  // positions in dig[]
+  const size_t a0 = (glo + 7) & ~(size_t)7, a1 = ghi & ~(size_t)7;
+  if (a0 < a1) {
+    for (size_t g = glo + threadIdx.x; g < a0; g += blockDim.x) count1(dig[g]);
+    const uint4* v4 = reinterpret_cast<const uint4*>(dig + a0);
+    const size_t nv = (a1 - a0) >> 3;
+    size_t i = threadIdx.x;
+    for (; i + blockDim.x < nv; i += 2 * (size_t)blockDim.x) {
+      const uint4 k0 = v4[i], k1 = v4[i + blockDim.x];
+      count8(k0);
+      count8(k1);
+    }
+    if (i < nv) count8(v4[i]);
+    for (size_t g = a1 + threadIdx.x; g < ghi; g += blockDim.x) count1(dig[g]);
+  } else {
+    for (size_t g = glo + threadIdx.x; g < ghi; g += blockDim.x) count1(dig[g]);
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
@@ -562,14 +583,23 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
   // one pass: every lane keeps its (up to) 8 digits and their ranks within their bins in registers, so each entry
   // costs one LDS atomic and the digits are read once
   constexpr uint32_t PER = SORT_TILE1 / 1024;
+  static_assert(PER == 8, "eight digits per lane: one 16-byte load where the window's digits are 16-byte aligned");
   int my_v[PER];
   uint32_t my_rank[PER];
+  // lane t takes digits [lo + 8 t, lo + 8 t + 8): one 16-byte load when the window's row of dig[] is aligned (n a multiple
+  // of eight), else eight 2-byte loads; which lane ranks which digit makes no difference to the sort
+  const size_t i0 = lo + (size_t)threadIdx.x * PER;
+  if ((((size_t)w * n) & 7u) == 0 && i0 + PER <= hi) {
+    const uint4 k = *reinterpret_cast<const uint4*>(d + i0);
+    my_v[0] = (int16_t)(k.x & 0xFFFFu), my_v[1] = (int16_t)(k.x >> 16), my_v[2] = (int16_t)(k.y & 0xFFFFu), my_v[3] = (int16_t)(k.y >> 16);
+    my_v[4] = (int16_t)(k.z & 0xFFFFu), my_v[5] = (int16_t)(k.z >> 16), my_v[6] = (int16_t)(k.w & 0xFFFFu), my_v[7] = (int16_t)(k.w >> 16);
+  } else {
 #pragma unroll
-  for (uint32_t r = 0; r < PER; r++) {
-    const size_t i = lo + r * 1024u + threadIdx.x;
-    my_v[r] = i < hi ? (int)d[i] : 0;
-    if (my_v[r] != 0) my_rank[r] = atomicAdd(&h[(uint32_t)((my_v[r] < 0 ? -my_v[r] : my_v[r]) - 1) >> 8], 1u);
+    for (uint32_t r = 0; r < PER; r++) my_v[r] = i0 + r < hi ? (int)d[i0 + r] : 0;
   }
+#pragma unroll
+  for (uint32_t r = 0; r < PER; r++)
+    if (my_v[r] != 0) my_rank[r] = atomicAdd(&h[(uint32_t)((my_v[r] < 0 ? -my_v[r] : my_v[r]) - 1) >> 8], 1u);
   __syncthreads();
   {
     // exclusive scan over <= 128 bins: wave prefix sums by the first two waves, then the first wave's total
@@ -594,7 +624,7 @@ static __global__ void __launch_bounds__(1024) k_scatter_hi(const int16_t* __res
     if (v != 0) {
       const uint32_t b = (uint32_t)((v < 0 ? -v : v) - 1);
       const uint32_t pos = lstart[b >> 8] + my_rank[r];
-      buf_ent[pos] = (uint32_t)(lo + r * 1024u + threadIdx.x) | (v < 0 ? 0x80000000u : 0u);
+      buf_ent[pos] = (uint32_t)(i0 + r) | (v < 0 ? 0x80000000u : 0u);
       buf_lo[pos] = (uint8_t)(b & 255u);
       buf_bin[pos] = (uint8_t)(b >> 8);
     }
