@@ -1063,30 +1063,35 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
   if (seg_plain) Q::store(seg_plain + g, q, run);
 }
 
-// one block per window: tree-sum seg[w*T .. w*T+T) into seg[w*T]
+// Tree-sum of the segment sums of a row (a window; table mode: a bucket group's weighted or unweighted sums).  Block
+// (row, chunk) adds the n entries s[j * stride], j < n, of its chunk s = seg + row * T + chunk * n * stride into s[0].  One
+// launch with n = T when a block's quads cover the row; else two: chunks of one entry per quad (stride 1), then the chunk
+// heads (stride = chunk length, `final`) -- a row of 2048 sums is then 11 dependent additions instead of 15 (Fq), 22
+// (Fq2, 128 quads a block) or 37 (BLS12-377 Fq2, 64 quads).  `final`: the result is what the host reads (stored form).
 template <class F>
-__global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T) {
-  XYZZ<F>* s = seg + (size_t)blockIdx.x * T;  // (table mode: the unweighted sums follow as gridDim.x / 2 more rows)
+__global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T, uint32_t n, uint32_t stride,
+                                                            int final) {
+  XYZZ<F>* s = seg + (size_t)blockIdx.x * T + (size_t)blockIdx.y * n * stride;
   using Q = QuadOps<F>;
   const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
-  if (T == 1) {  // nothing to add: the row's one segment sum only changes form
-    if (qi == 0) Q::store_final(s, q, Q::load(s, q));
+  if (n == 1) {  // nothing to add: the one sum only changes form
+    if (qi == 0 && final) Q::store_final(s, q, Q::load(s, q));
     return;
   }
-  if (T > nq) {  // fold the tail onto the first nq entries
-    typename Q::Coord a = Q::load(s + qi, q);
-    for (uint32_t j = qi + nq; j < T; j += nq) a = Q::add(a, Q::load(s + j, q), q);
-    Q::store(s + qi, q, a);
+  if (n > nq) {  // fold the tail onto the first nq entries
+    typename Q::Coord a = Q::load(s + (size_t)qi * stride, q);
+    for (uint32_t j = qi + nq; j < n; j += nq) a = Q::add(a, Q::load(s + (size_t)j * stride, q), q);
+    Q::store(s + (size_t)qi * stride, q, a);
     __syncthreads();
-    T = nq;
+    n = nq;
   }
-  for (uint32_t h = T >> 1; h >= 1; h >>= 1) {
+  for (uint32_t h = n >> 1; h >= 1; h >>= 1) {
     if (qi < h) {
-      const typename Q::Coord r = Q::add(Q::load(s + qi, q), Q::load(s + qi + h, q), q);
-      if (h == 1)
-        Q::store_final(s, q, r);  // the row's sum, read by the host: the library's stored form
+      const typename Q::Coord r = Q::add(Q::load(s + (size_t)qi * stride, q), Q::load(s + (size_t)(qi + h) * stride, q), q);
+      if (h == 1 && final)
+        Q::store_final(s, q, r);
       else
-        Q::store(s + qi, q, r);
+        Q::store(s + (size_t)qi * stride, q, r);
     }
     __syncthreads();
   }

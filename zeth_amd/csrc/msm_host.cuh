@@ -367,10 +367,20 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                      p.k, p.L, (uint32_t)p.W, seg, tab ? seg + (size_t)p.W * p.T : (XYZZ<F>*)nullptr);
   ctx->mark("reduce2");
   {
-    uint32_t t2 = 4 * p.T;  // a quad per entry, up to the block the field's registers allow; at least a wave
-    if (t2 > (uint32_t)quad_block<F>()) t2 = quad_block<F>();
-    if (t2 < 64) t2 = 64;
-    hipLaunchKernelGGL((k_reduce2<F>), dim3(rows), dim3(t2), 0, st, seg, p.T);
+    const uint32_t nq = (uint32_t)quad_block<F>() / 4;  // quads of a full block
+    if (p.T > nq && p.T % nq == 0) {
+      // chunks of one entry per quad, then the chunk heads
+      hipLaunchKernelGGL((k_reduce2<F>), dim3(rows, p.T / nq), dim3(4 * nq), 0, st, seg, p.T, nq, 1u, 0);
+      uint32_t t2 = 4 * (p.T / nq);
+      if (t2 > 4 * nq) t2 = 4 * nq;
+      if (t2 < 64) t2 = 64;
+      hipLaunchKernelGGL((k_reduce2<F>), dim3(rows, 1), dim3(t2), 0, st, seg, p.T, p.T / nq, nq, 1);
+    } else {
+      uint32_t t2 = 4 * p.T;  // a quad per entry, up to the block the field's registers allow; at least a wave
+      if (t2 > 4 * nq) t2 = 4 * nq;
+      if (t2 < 64) t2 = 64;
+      hipLaunchKernelGGL((k_reduce2<F>), dim3(rows, 1), dim3(t2), 0, st, seg, p.T, p.T, 1u, 1);
+    }
   }
   ctx->mark("end");
   ZG_HIP(hipGetLastError());
