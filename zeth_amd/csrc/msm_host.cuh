@@ -250,7 +250,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->prof_begin();
   ctx->mark("digits");
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
-                     (size_t)(p.W + 1 + 64), heavy);
+                     (size_t)(p.W + 1 + 64), heavy, gcnt, (size_t)(tab ? 129 : 0));
   uint32_t* dense_counters = ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr;
   if (tab) {
     // level 0 of the sort: entries by bucket group
@@ -258,7 +258,8 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     if (tile_scalars > 1024) tile_scalars = 1024;
     size_t cblocks = (n + 255) / 256;
     if (cblocks > 2048) cblocks = 2048;
-    ZG_HIP(hipMemsetAsync(gcnt, 0, 129 * 4, st));
+    // (k_table_starts stays a launch of its own: folding it into the last workgroup of k_table_count needs a device-wide
+    // fence per workgroup, which on this part writes back and invalidates an XCD's L2 -- digits phase 0.78 -> 1.07 ms)
     hipLaunchKernelGGL((k_table_count<Fr>), dim3((unsigned)cblocks), dim3(256), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K,
                        (uint32_t)p.W - 1u, gcnt, dense_counters);
     hipLaunchKernelGGL(k_table_starts, dim3(1), dim3(64), 0, st, gcnt, (uint32_t)p.W, gstart, gcursor);
