@@ -348,8 +348,8 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                        order, sorted, d_bases, part, zg_debug_base_mask(), w_lo, 0u);
   }
   ctx->mark("combine");
-  hipLaunchKernelGGL((k_combine_light<F>), dim3((4 * p.cap + 255) / 256, p.W), dim3(256), 0, st, units, wunits, (uint32_t)p.W,
-                     p.cap, cnt, ufirst, p.L, part, p.smax);
+  hipLaunchKernelGGL((k_combine_light<F>), dim3((4 * p.nb + 255) / 256, p.W), dim3(256), 0, st, wunits, (uint32_t)p.W, p.nb, cnt,
+                     ufirst, p.L, part, p.smax);
   {
     uint32_t chunks = (p.cap + COMBINE_CHUNK - 1) / COMBINE_CHUNK;
     if (chunks > 64) chunks = 64;
