@@ -264,10 +264,7 @@ struct ProvingKeyDev : PkBase {
       // The lanes' evaluations are off the proof's critical path (the H chain on the main stream): 128 bucket segments a
       // window instead of 1024 cut their reduction's instruction count 2.6x (profiles/r2_prove_valu_by_kernel.txt: the
       // reductions were 37 % of a proof's vector instructions), worth +10 % proofs/s with four proofs in flight.
-      static const int lane_t = getenv("ZG_PROVE_LANE_SEGMENTS") ? atoi(getenv("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knobs
-      static const int lane_t_g2 = getenv("ZG_PROVE_G2_SEGMENTS") ? atoi(getenv("ZG_PROVE_G2_SEGMENTS")) : 256;
-      const int t = (&l == &lane[0]) ? lane_t_g2 : lane_t;  // lane 0 runs the G2 evaluation, whose additions cost 3x
-      l->reduce_segments = (t > 0 && (t & (t - 1)) == 0) ? (uint32_t)t : 0u;
+      // (set per proof in prove_impl: lane_segments())
     }  // the SAME priority as the main stream.  With the lanes one level below it (default or lowest priority, both tried,
        // rounds 1 and 2) a proof does not complete within 90 s: no fault, the process stays killable, and with equal
        // priorities the same queue of work takes 4 ms -- the lanes' queues are not served while the high-priority queue
@@ -403,6 +400,16 @@ struct ProvingKeyDev : PkBase {
     // A proof is ~100 kernel launches and the host needs 20-35 us for each: queued from one thread, the last lane's
     // first kernel started 3.3 ms after the proof began (rocprofv3 timeline, JoinSplit scale) although its input was
     // ready after 0.05 ms.  Every lane is therefore queued by a thread of its own while this thread queues the H chain.
+    // Few, long segments only while the evaluation is small: with 2^16 or more dense scalars the accumulation dwarfs the
+    // reduction's instructions and its longer chain is what shows (BLS12-377, 2^20 constraints, 105 K dense scalars: 13.1 -> 12.2 ms with the
+    // plan's own segment count).
+    static const int lane_t = getenv("ZG_PROVE_LANE_SEGMENTS") ? atoi(getenv("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knobs
+    static const int lane_t_g2 = getenv("ZG_PROVE_G2_SEGMENTS") ? atoi(getenv("ZG_PROVE_G2_SEGMENTS")) : 256;
+    for (int i = 0; i < 4; i++) {
+      const int t = i == 0 ? lane_t_g2 : lane_t;  // lane 0 runs the G2 evaluation, whose additions cost 3x
+      const bool small = dense_hint[i] < (1u << 16);
+      lane[i]->reduce_segments = (small && t > 0 && (t & (t - 1)) == 0) ? (uint32_t)t : 0u;
+    }
     int lane_status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
     auto queue_lane = [&](int i) {
       if (hipSetDevice(ctx->device) != hipSuccess) {
