@@ -115,6 +115,14 @@ inline int msm_pick_c(size_t n) {
 // weighting of each one to the work (2^24 points, c = 22, 64 groups: 2048 segments a group 1.39 ms, 512 segments 1.00 ms)
 inline void msm_cap_segments(MsmPlan& p) {
   while (p.T > 256 && (size_t)p.T * (size_t)p.W > 40000) p.T >>= 1;
+  // ... and with few windows or groups, more and shorter segments while the quads stay within a wave per SIMD: the chain
+  // of a segment (2 k additions + the weighting) is the latency of the whole reduction then
+  // (measurement knob: with few windows or groups, more and shorter segments up to this many quads -- inside a proof it
+  // made no difference: c = 17, 2048 / 4096 / 8192 segments a group 384 / 388 / 388 proofs/s)
+  if (const char* e = getenv("ZG_MSM_MORE_SEGMENTS")) {
+    const size_t lim = strtoul(e, nullptr, 0);
+    while (p.T < p.nb / 4 && (size_t)p.T * (size_t)p.W * 2 <= lim) p.T <<= 1;
+  }
 }
 
 inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {

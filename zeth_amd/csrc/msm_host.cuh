@@ -270,6 +270,9 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     else if (p.c == 20 && p.D == msm_table_digits(Fr::Params::BITS, 20))
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 20>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
                          (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+    else if (p.c == 17 && p.D == msm_table_digits(Fr::Params::BITS, 17))  // (the prover's H table up to 2^19 points)
+      hipLaunchKernelGGL((k_table_scatter_static<Fr, 17>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
     else
       hipLaunchKernelGGL((k_table_scatter<Fr>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K, p.gbits,
                          (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);

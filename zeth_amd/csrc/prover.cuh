@@ -210,7 +210,12 @@ struct ProvingKeyDev : PkBase {
       if (table_min && v->H_len + 1 >= table_min && v->H_len >= 1024) {  // H_len = domain size - 1
         int c = 0, D = 0;
         static const int h_table_c = getenv("ZG_PK_TABLE_C") ? atoi(getenv("ZG_PK_TABLE_C")) : 0;  // tuning knob
-        ZG_TRY(o1->table_params(v->H_len, h_table_c, &c, &D));
+        // Up to 2^19 points a 17-bit table (15 digits, 2^16 buckets in two groups) instead of the lone evaluation's 20 bits:
+        // alone the two take the same time, inside a proof the eight times smaller reduction leaves the device to the
+        // other evaluations (JoinSplit shape, four proofs in flight: 375 -> 385-398 proofs/s, latency unchanged).  From
+        // 2^20 points on 20 bits win alone and inside a proof (BLS12-377, 2^20 constraints: 11.9 against 12.9 ms).
+        const int want_c = h_table_c ? h_table_c : (v->H_len < ((size_t)1 << 19) ? 17 : 0);
+        ZG_TRY(o1->table_params(v->H_len, want_c, &c, &D));
         if ((uint64_t)D * v->H_len < (1ull << 31)) {
           Affine<Fq>* table = nullptr;
           if (hipMalloc((void**)&table, (size_t)D * v->H_len * sizeof(Affine<Fq>)) != hipSuccess) {
