@@ -8,7 +8,7 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/zeth_gpu.h
 
-all: zeth_amd/libzeth_gpu.so host
+all: zeth_amd/libzeth_gpu.so host dbg
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -17,10 +17,23 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 zeth_amd/libzeth_gpu.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
+# The same sources with -DZG_DEBUG_KNOBS: the tuning / measurement / fault-injection knobs of csrc/knobs.h are compiled in.
+# For tools/ and for the one test that injects a failure (select it with ZETH_GPU_LIBRARY); never the shipped library.
+DBGDIR := build/dbg
+DBGOBJS := $(patsubst $(CSRC)/%.hip,$(DBGDIR)/%.o,$(SRCS))
+$(DBGDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(DBGDIR)
+	$(HIPCC) $(HIPFLAGS) -DZG_DEBUG_KNOBS -c $< -o $@
+
+$(DBGDIR)/libzeth_gpu.so: $(DBGOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(DBGOBJS) -o $@
+
+dbg: $(DBGDIR)/libzeth_gpu.so
+
 clean:
 	rm -rf $(OBJDIR) zeth_amd/libzeth_gpu.so
 
-.PHONY: all clean host
+.PHONY: all clean host dbg
 
 # C++ host module above the C ABI (include/libzeth_gpu/): the zeth-tool `prove` counterpart and the adapter test driver
 HOSTCXX ?= g++

@@ -19,19 +19,6 @@
 namespace libzeth_gpu
 {
 
-/// r1cs_gg_ppzksnark_verification_key<ppT> as this fork's verifier uses it (gamma is the G2 generator: SURVEY KAT-6)
-template<typename ppT> struct r1cs_gg_ppzksnark_verification_key {
-    G1<ppT> alpha_g1;
-    G2<ppT> beta_g2;
-    G2<ppT> delta_g2;
-    G1_vector<ppT> ABC_g1; // num_inputs + 1
-};
-
-template<typename ppT> struct r1cs_gg_ppzksnark_keypair {
-    r1cs_gg_ppzksnark_proving_key<ppT> pk;
-    r1cs_gg_ppzksnark_verification_key<ppT> vk;
-};
-
 namespace internal
 {
 
@@ -350,14 +337,18 @@ r1cs_gg_ppzksnark_keypair<ppT> r1cs_gg_ppzksnark_generator_from_secrets(
     kp.vk.alpha_g1 = kp.pk.alpha_g1;
     kp.vk.beta_g2 = kp.pk.beta_g2;
     kp.vk.delta_g2 = kp.pk.delta_g2;
-    kp.vk.ABC_g1 = internal::batch_exp<ppT, G1<ppT>>(abc_sc);
+    kp.vk.ABC_g1 = accumulation_vector<G1<ppT>>(internal::batch_exp<ppT, G1<ppT>>(abc_sc));
     return kp;
 }
 
-/// r1cs_gg_ppzksnark_generator<ppT>(cs, true): the secrets drawn from the OS entropy source (t outside the domain and
-/// delta non-zero with overwhelming probability; redrawn otherwise)
+/// r1cs_gg_ppzksnark_generator<ppT>(cs, true): like libsnark's, it works on a copy of the system with
+/// swap_AB_if_beneficial() applied (the from-secrets form above does NOT swap: callers that compare the two apply the
+/// swap themselves, mpc_test.cpp:42,164,340), and the key carries that copy.  The secrets are drawn from the OS entropy
+/// source (t outside the domain and delta non-zero with overwhelming probability; redrawn otherwise).
 template<typename ppT> r1cs_gg_ppzksnark_keypair<ppT> r1cs_gg_ppzksnark_generator(const r1cs_constraint_system<Fr<ppT>> &cs)
 {
+    r1cs_constraint_system<Fr<ppT>> cs_copy(cs);
+    cs_copy.swap_AB_if_beneficial();
     for (;;) {
         const Fr<ppT> t = random_field_element<ppT>(), alpha = random_field_element<ppT>(), beta = random_field_element<ppT>(),
                       delta = random_field_element<ppT>();
@@ -365,7 +356,7 @@ template<typename ppT> r1cs_gg_ppzksnark_keypair<ppT> r1cs_gg_ppzksnark_generato
             continue;
         }
         try {
-            return r1cs_gg_ppzksnark_generator_from_secrets<ppT>(cs, t, alpha, beta, delta);
+            return r1cs_gg_ppzksnark_generator_from_secrets<ppT>(cs_copy, t, alpha, beta, delta);
         } catch (const std::invalid_argument &e) {
             if (std::string(e.what()).find("evaluation domain") == std::string::npos) {
                 throw;
@@ -378,27 +369,6 @@ template<typename ppT> r1cs_gg_ppzksnark_keypair<ppT> r1cs_gg_ppzksnark_generato
 template<typename ppT> r1cs_gg_ppzksnark_keypair<ppT> generate_setup(const r1cs_constraint_system<Fr<ppT>> &cs)
 {
     return r1cs_gg_ppzksnark_generator<ppT>(cs);
-}
-
-/// groth16_snark<ppT>::verification_key_write_bytes (groth16_snark.tcc:77-91): alpha_g1, beta_g2, delta_g2, then ABC_g1
-/// as libsnark's accumulation_vector -- the first element, then the rest as a sparse vector whose indices are 0..n-1
-/// (stream_utils.tcc:111-139)
-template<typename ppT> void verification_key_write_bytes(const r1cs_gg_ppzksnark_verification_key<ppT> &vk, std::ostream &out_s)
-{
-    if (vk.ABC_g1.empty()) {
-        throw std::invalid_argument("verification key (write) not well-formed");
-    }
-    group_element_write_bytes(vk.alpha_g1, out_s);
-    group_element_write_bytes(vk.beta_g2, out_s);
-    group_element_write_bytes(vk.delta_g2, out_s);
-    group_element_write_bytes(vk.ABC_g1[0], out_s);
-    const size_t rest = vk.ABC_g1.size() - 1;
-    write_bytes(rest, out_s); // domain_size_
-    write_bytes(rest, out_s); // number of entries
-    for (size_t i = 0; i < rest; i++) {
-        write_bytes(i, out_s);
-        group_element_write_bytes(vk.ABC_g1[i + 1], out_s);
-    }
 }
 
 } // namespace libzeth_gpu

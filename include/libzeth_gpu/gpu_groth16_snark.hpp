@@ -14,6 +14,7 @@
 #define LIBZETH_GPU_GROTH16_SNARK_HPP
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -60,10 +61,15 @@ private:
 /// The proving key resident on the device: bases in HBM, constraint matrices as CSR, per-proof scratch.  The
 /// analogue of loading the keypair once before serving proofs (prover_server/prover_server.cpp:449-493,
 /// zeth_tool/prove_cmd.cpp:39-43).
+///
+/// One object = one prover: calls on it are serialised by its own mutex.  clone() gives ANOTHER prover over the same
+/// resident key (zg_pk_clone: shared bases and matrices, own scratch, streams and context), so that prove() on the
+/// clone overlaps prove() on the original -- how several proofs are kept in flight on one device.  Clones keep the
+/// uploaded key alive: the original may be destroyed first.
 template<typename ppT> class device_proving_key
 {
 public:
-    device_proving_key(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, int device = 0) : dcp_(device_context::get_shared(device)), dc_(*dcp_), handle_(nullptr)
+    device_proving_key(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, int device = 0) : root_(new root(device)), handle_(nullptr), call_mutex_(&root_->dc.mutex())
     {
         using FieldT = Fr<ppT>;
         const r1cs_constraint_system<FieldT> &cs = pk.constraint_system;
@@ -131,16 +137,29 @@ public:
         v.L_query = pk.L_query.data();
         v.L_len = pk.L_query.size();
         v.form = ZG_FORM_PLAIN;
-        std::lock_guard<std::mutex> lock(dc_.mutex());
-        check(zg_pk_create(dc_.ctx(), ppT::curve_id, &v, &handle_));
+        std::lock_guard<std::mutex> lock(root_->dc.mutex());
+        check(zg_pk_create(root_->dc.ctx(), ppT::curve_id, &v, &root_->handle));
+        handle_ = root_->handle;
     }
     ~device_proving_key()
     {
-        std::lock_guard<std::mutex> lock(dc_.mutex());
-        zg_pk_free(handle_);
+        if (handle_ && handle_ != root_->handle) {
+            zg_pk_free(handle_); // a clone: its own context, nothing shared with other callers
+        }
+        // the uploaded key itself goes with the last object that refers to it (root's destructor)
     }
     device_proving_key(const device_proving_key &) = delete;
     device_proving_key &operator=(const device_proving_key &) = delete;
+
+    /// A second prover over the same resident key, for another calling thread (zg_pk_clone)
+    std::unique_ptr<device_proving_key> clone() const
+    {
+        std::unique_ptr<device_proving_key> c(new device_proving_key(root_));
+        std::lock_guard<std::mutex> lock(root_->dc.mutex()); // the original must not be proving while it is cloned
+        check(zg_pk_clone(root_->handle, &c->handle_));
+        return c;
+    }
+    bool is_clone() const { return handle_ != root_->handle; }
 
     size_t domain_size() const
     {
@@ -155,7 +174,7 @@ public:
     {
         r1cs_gg_ppzksnark_proof<ppT> proof;
         static_assert(sizeof(proof) == 2 * sizeof(G1<ppT>) + sizeof(G2<ppT>), "proof must be g_A || g_B || g_C without padding");
-        std::lock_guard<std::mutex> lock(dc_.mutex());
+        std::lock_guard<std::mutex> lock(*call_mutex_);
         check(zg_prove(
             handle_, primary.data(), primary.size(), auxiliary.data(), auxiliary.size(), ZG_FORM_PLAIN, r.data, s.data, ZG_FORM_PLAIN, &proof));
         return proof;
@@ -165,16 +184,34 @@ public:
     std::vector<Fr<ppT>> witness_map(const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary) const
     {
         std::vector<Fr<ppT>> h(domain_size() + 1);
-        std::lock_guard<std::mutex> lock(dc_.mutex());
+        std::lock_guard<std::mutex> lock(*call_mutex_);
         check(zg_witness_map(
             handle_, primary.data(), primary.size(), auxiliary.data(), auxiliary.size(), ZG_FORM_PLAIN, ZG_FORM_PLAIN, h.data()));
         return h;
     }
 
 private:
-    std::shared_ptr<device_context> dcp_; // keeps the context alive for as long as the key
-    device_context &dc_;
+    // the uploaded key: lives on the device's shared context (whose mutex serialises every call on that context) and
+    // is freed with the last prover that refers to it
+    struct root {
+        std::shared_ptr<device_context> dcp; // keeps the context alive for as long as the key
+        device_context &dc;
+        zg_pk *handle;
+        explicit root(int device) : dcp(device_context::get_shared(device)), dc(*dcp), handle(nullptr) {}
+        ~root()
+        {
+            if (handle) {
+                std::lock_guard<std::mutex> lock(dc.mutex());
+                zg_pk_free(handle);
+            }
+        }
+    };
+    explicit device_proving_key(const std::shared_ptr<root> &r) : root_(r), handle_(nullptr), call_mutex_(&own_mutex_) {}
+    // declared first, destroyed last: a clone's handle is freed (destructor body) before the key it was cloned from
+    std::shared_ptr<root> root_;
     zg_pk *handle_;
+    mutable std::mutex own_mutex_; // a clone has a context of its own: only calls on THIS object exclude each other
+    std::mutex *call_mutex_;       // the original computes on the device's shared context: that context's mutex
 };
 
 /// Fr::random_element(): uniform in [0, r) from the OS entropy source (libsnark draws the prover's r and s this
@@ -195,32 +232,49 @@ template<typename ppT> Fr<ppT> random_field_element()
     }
 }
 
-/// One resident copy of the proving key per device, provers handed out round-robin: prover_server's handlers
-/// (prover_server/prover_server.cpp:192-201) call prove() concurrently and every call runs on the next device's key.
-/// Independent proofs are replicas -- no exchange between devices.  One process, N devices.
+/// Proofs in flight across devices and within each device: one resident copy of the proving key per device and up to
+/// `in_flight_per_device` provers over it (the original + zg_pk_clone clones, created when first needed).  prove() takes
+/// a free prover -- on the device with the fewest proofs in flight -- and blocks only when every prover of every device
+/// is busy.  This is what prover_server's concurrent handlers (prover_server/prover_server.cpp:118-201; one shared
+/// keypair, :51,451) call into: K handler threads keep K proofs in flight (BASELINE configs[4]).  Independent proofs are
+/// replicas -- no exchange between devices.  One process, N devices.
 template<typename ppT> class device_proving_key_pool
 {
 public:
-    device_proving_key_pool(const r1cs_gg_ppzksnark_proving_key<ppT> &pk, const std::vector<int> &devices) : next_(0)
+    static constexpr size_t default_in_flight_per_device = 4; // measured: 2 / 4 / 8 in flight = 300 / 385 / 250 proofs/s
+
+    device_proving_key_pool(
+        const r1cs_gg_ppzksnark_proving_key<ppT> &pk, const std::vector<int> &devices, size_t in_flight_per_device = default_in_flight_per_device)
+        : max_per_device_(in_flight_per_device ? in_flight_per_device : 1), in_flight_(0), peak_in_flight_(0), proofs_(0)
     {
         if (devices.empty()) {
             throw std::invalid_argument("device_proving_key_pool: no devices");
         }
         for (int d : devices) {
-            keys_.emplace_back(new device_proving_key<ppT>(pk, d));
+            std::unique_ptr<device_state> st(new device_state());
+            st->slots.emplace_back(new slot{std::unique_ptr<device_proving_key<ppT>>(new device_proving_key<ppT>(pk, d)), false});
+            devices_.push_back(std::move(st));
         }
     }
-    size_t size() const { return keys_.size(); }
+    size_t size() const { return devices_.size(); }
+    size_t in_flight_per_device() const { return max_per_device_; }
+    /// the largest number of proofs that were in flight at once, and the proofs completed, since construction
+    size_t peak_in_flight() const
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        return peak_in_flight_;
+    }
+    size_t proofs_completed() const
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        return proofs_;
+    }
+
     r1cs_gg_ppzksnark_proof<ppT> prove(
         const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary, const Fr<ppT> &r, const Fr<ppT> &s)
     {
-        size_t k;
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            k = next_;
-            next_ = (next_ + 1) % keys_.size();
-        }
-        return keys_[k]->prove(primary, auxiliary, r, s); // serialised per device by the device context's mutex
+        lease l(*this);
+        return l.prover().prove(primary, auxiliary, r, s);
     }
     r1cs_gg_ppzksnark_proof<ppT> prove(const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary)
     {
@@ -228,14 +282,100 @@ public:
     }
 
 private:
-    std::vector<std::unique_ptr<device_proving_key<ppT>>> keys_;
-    std::mutex m_;
-    size_t next_;
+    struct slot {
+        std::unique_ptr<device_proving_key<ppT>> prover;
+        bool busy;
+    };
+    struct device_state {
+        std::vector<std::unique_ptr<slot>> slots; // slots[0] holds the uploaded key, the others are its clones
+        size_t busy = 0;
+        size_t growing = 0; // clones being created (outside the pool's lock)
+    };
+    // one proof's hold on a prover; released on every exit path
+    class lease
+    {
+    public:
+        explicit lease(device_proving_key_pool &pool) : pool_(pool), dev_(nullptr), slot_(nullptr)
+        {
+            std::unique_lock<std::mutex> lock(pool_.m_);
+            for (;;) {
+                // the device with the fewest proofs in flight that still has, or may still create, a free prover
+                device_state *best = nullptr;
+                for (auto &d : pool_.devices_) {
+                    const bool has_free = d->busy < d->slots.size();
+                    const bool can_grow = d->slots.size() + d->growing < pool_.max_per_device_;
+                    if ((has_free || can_grow) && (!best || d->busy + d->growing < best->busy + best->growing)) {
+                        best = d.get();
+                    }
+                }
+                if (!best) {
+                    pool_.cv_.wait(lock);
+                    continue;
+                }
+                dev_ = best;
+                for (auto &sl : best->slots) {
+                    if (!sl->busy) {
+                        slot_ = sl.get();
+                        break;
+                    }
+                }
+                if (!slot_) {
+                    // every prover of this device is busy and it may have more: clone the key's prover without holding
+                    // the pool (a clone allocates its scratch and streams: milliseconds)
+                    best->growing++;
+                    lock.unlock();
+                    std::unique_ptr<slot> fresh;
+                    try {
+                        fresh.reset(new slot{best->slots[0]->prover->clone(), true});
+                    } catch (...) {
+                        lock.lock();
+                        best->growing--;
+                        pool_.cv_.notify_all();
+                        throw;
+                    }
+                    lock.lock();
+                    best->growing--;
+                    slot_ = fresh.get();
+                    best->slots.push_back(std::move(fresh));
+                }
+                slot_->busy = true;
+                best->busy++;
+                pool_.in_flight_++;
+                if (pool_.in_flight_ > pool_.peak_in_flight_) {
+                    pool_.peak_in_flight_ = pool_.in_flight_;
+                }
+                return;
+            }
+        }
+        ~lease()
+        {
+            std::lock_guard<std::mutex> lock(pool_.m_);
+            slot_->busy = false;
+            dev_->busy--;
+            pool_.in_flight_--;
+            pool_.proofs_++;
+            pool_.cv_.notify_one();
+        }
+        lease(const lease &) = delete;
+        const device_proving_key<ppT> &prover() const { return *slot_->prover; }
+
+    private:
+        device_proving_key_pool &pool_;
+        device_state *dev_;
+        slot *slot_;
+    };
+
+    std::vector<std::unique_ptr<device_state>> devices_;
+    const size_t max_per_device_;
+    mutable std::mutex m_;
+    std::condition_variable cv_;
+    size_t in_flight_, peak_in_flight_, proofs_;
 };
 
 namespace internal
 {
-// Device keys built by the stateless entry points, by host key address.  A fingerprint over the key's sizes, its
+// Device keys built by the stateless entry points, by host key address: each a pool of provers over one uploaded key
+// (device 0; up to stateless_in_flight() proofs of concurrent callers overlap, as prover_server's handlers need).  A fingerprint over the key's sizes, its
 // single elements, samples of all four queries (B included) and of the constraint system guards against a different
 // or modified key at the same address.  At most MAX_KEYS device keys are kept (least recently used goes first: a
 // device key can hold 12-13 times its H query); release_device_keys() drops them all, and runs by itself at exit while
@@ -245,7 +385,7 @@ template<typename ppT> struct device_key_cache {
     struct entry {
         uint64_t fingerprint;
         uint64_t last_use;
-        std::shared_ptr<device_proving_key<ppT>> key;
+        std::shared_ptr<device_proving_key_pool<ppT>> key;
     };
     struct state {
         std::mutex m;
@@ -316,7 +456,7 @@ template<typename ppT> struct device_key_cache {
         std::lock_guard<std::mutex> lock(s.m);
         s.cache.clear();
     }
-    static std::shared_ptr<device_proving_key<ppT>> lookup(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
+    static std::shared_ptr<device_proving_key_pool<ppT>> lookup(const r1cs_gg_ppzksnark_proving_key<ppT> &pk)
     {
         state &s = st();
         std::lock_guard<std::mutex> lock(s.m);
@@ -338,7 +478,7 @@ template<typename ppT> struct device_key_cache {
             }
             s.cache.erase(oldest);
         }
-        entry e{fp, ++s.clock, std::make_shared<device_proving_key<ppT>>(pk)};
+        entry e{fp, ++s.clock, std::make_shared<device_proving_key_pool<ppT>>(pk, std::vector<int>{0})};
         s.cache[&pk] = e;
         if (!s.exit_hook) {
             // registered after the first key exists, hence after the HIP runtime came up: at exit this runs before the
@@ -356,7 +496,8 @@ template<typename ppT> struct device_key_cache {
 template<typename ppT> void release_device_keys() { internal::device_key_cache<ppT>::release_all(); }
 
 /// libsnark::r1cs_gg_ppzksnark_prover as Zeth calls it.  The key is uploaded on first use and stays resident for the
-/// process lifetime.  Zeth always passes force_pow_2_domain = true (groth16_snark.tcc:43-45); the device transforms
+/// process lifetime.  Concurrent calls with one key overlap on the device (up to
+/// device_proving_key_pool::default_in_flight_per_device proofs in flight; further callers wait for a free prover).  Zeth always passes force_pow_2_domain = true (groth16_snark.tcc:43-45); the device transforms
 /// are radix-2 only, so false is rejected.
 template<typename ppT>
 r1cs_gg_ppzksnark_proof<ppT> r1cs_gg_ppzksnark_prover(
@@ -368,8 +509,8 @@ r1cs_gg_ppzksnark_proof<ppT> r1cs_gg_ppzksnark_prover(
     if (!force_pow_2_domain) {
         throw std::invalid_argument("r1cs_gg_ppzksnark_prover: only power-of-two domains are supported");
     }
-    const std::shared_ptr<device_proving_key<ppT>> dpk = internal::device_key_cache<ppT>::lookup(pk);
-    return dpk->prove(primary_input, auxiliary_input, random_field_element<ppT>(), random_field_element<ppT>());
+    const std::shared_ptr<device_proving_key_pool<ppT>> provers = internal::device_key_cache<ppT>::lookup(pk);
+    return provers->prove(primary_input, auxiliary_input, random_field_element<ppT>(), random_field_element<ppT>());
 }
 
 template<typename ppT> bool container_is_well_formed(const G1_vector<ppT> &points)
@@ -411,12 +552,25 @@ template<typename ppT> bool is_well_formed(const r1cs_gg_ppzksnark_proving_key<p
     return true;
 }
 
-/// The proving half of libzeth::groth16_snark<ppT> (groth16_snark.hpp:15-79).  Setup and verification stay with
-/// libsnark on the CPU: they are outside the accelerated path.
+/// groth16_snark.tcc:215-224
+template<typename ppT> bool is_well_formed(const r1cs_gg_ppzksnark_verification_key<ppT> &vk)
+{
+    if (!group_element_is_well_formed<ppT>(vk.alpha_g1) || !group_element_is_well_formed<ppT>(vk.beta_g2) ||
+        !group_element_is_well_formed<ppT>(vk.delta_g2) || !group_element_is_well_formed<ppT>(vk.ABC_g1.first)) {
+        return false;
+    }
+    return container_is_well_formed<ppT>(vk.ABC_g1.rest.values);
+}
+
+/// The proving half of libzeth::groth16_snark<ppT> (groth16_snark.hpp:15-79) and the key / proof codecs its callers use
+/// (prover_server.cpp:462,475,482,490; prove_cmd.cpp:39-62).  generate_setup is in gpu_groth16_generator.hpp;
+/// verification stays with libsnark on the CPU: it is outside the accelerated path.
 template<typename ppT> class groth16_snark
 {
 public:
     using proving_key = r1cs_gg_ppzksnark_proving_key<ppT>;
+    using verification_key = r1cs_gg_ppzksnark_verification_key<ppT>;
+    using keypair = r1cs_gg_ppzksnark_keypair<ppT>;
     using proof = r1cs_gg_ppzksnark_proof<ppT>;
 
     static constexpr const char *name = "GROTH16";
@@ -466,6 +620,56 @@ public:
         if (!is_well_formed<ppT>(pk)) {
             throw std::invalid_argument("proving key (read) not well-formed");
         }
+    }
+
+    /// groth16_snark.tcc:76-91
+    static void verification_key_write_bytes(const verification_key &vk, std::ostream &out_s)
+    {
+        if (!is_well_formed<ppT>(vk)) {
+            throw std::invalid_argument("verification key (write) not well-formed");
+        }
+        group_element_write_bytes(vk.alpha_g1, out_s);
+        group_element_write_bytes(vk.beta_g2, out_s);
+        group_element_write_bytes(vk.delta_g2, out_s);
+        accumulation_vector_write_bytes(vk.ABC_g1, out_s);
+    }
+
+    /// groth16_snark.tcc:113-128
+    static void verification_key_read_bytes(verification_key &vk, std::istream &in_s)
+    {
+        group_element_read_bytes(vk.alpha_g1, in_s);
+        group_element_read_bytes(vk.beta_g2, in_s);
+        group_element_read_bytes(vk.delta_g2, in_s);
+        accumulation_vector_read_bytes(vk.ABC_g1, in_s);
+        if (!is_well_formed<ppT>(vk)) {
+            throw std::invalid_argument("verification key (read) not well-formed");
+        }
+    }
+
+    /// groth16_snark.tcc:58-74
+    static void verification_key_write_json(const verification_key &vk, std::ostream &out_s)
+    {
+        const size_t abc_length = vk.ABC_g1.rest.indices.size() + 1;
+        out_s << "{\n  \"alpha\": " << group_element_to_json(vk.alpha_g1) << ",\n  \"beta\": " << group_element_to_json(vk.beta_g2)
+              << ",\n  \"delta\": " << group_element_to_json(vk.delta_g2) << ",\n  \"ABC\": [\n    " << group_element_to_json(vk.ABC_g1.first);
+        for (size_t i = 1; i < abc_length; ++i) {
+            out_s << ",\n    " << group_element_to_json(vk.ABC_g1.rest.values[i - 1]);
+        }
+        out_s << "\n  ]\n}";
+    }
+
+    /// groth16_snark.tcc:177-191: the proving key, then the verification key -- the file prover_server keeps as
+    /// ~/zeth_setup/keypair.bin (prover_server.cpp:456-463, 487-490)
+    static void keypair_write_bytes(const keypair &keypair, std::ostream &out_s)
+    {
+        proving_key_write_bytes(keypair.pk, out_s);
+        verification_key_write_bytes(keypair.vk, out_s);
+    }
+
+    static void keypair_read_bytes(keypair &keypair, std::istream &in_s)
+    {
+        proving_key_read_bytes(keypair.pk, in_s);
+        verification_key_read_bytes(keypair.vk, in_s);
     }
 
     static void proof_write_bytes(const proof &proof, std::ostream &out_s)
@@ -547,27 +751,24 @@ public:
             throw std::invalid_argument("sharded_bases: no devices");
         }
         const size_t n = gs.size(), k = devices.size();
-        for (size_t i = 0; i < k; i++) {
-            const size_t lo = n * i / k, hi = n * (i + 1) / k;
-            zg_ctx *c = nullptr;
-            check(zg_ctx_create(devices[i], &c)); // a context of its own per shard: shards run concurrently
-            ctxs_.push_back(c);
-            zg_bases *b = nullptr;
-            check(zg_bases_create(c, ppT::curve_id, GroupT::group_id, gs.data() + lo, hi - lo, ZG_FORM_PLAIN, ZG_MEM_HOST, &b));
-            shards_.push_back(b);
-            first_.push_back(lo);
+        try {
+            for (size_t i = 0; i < k; i++) {
+                const size_t lo = n * i / k, hi = n * (i + 1) / k;
+                zg_ctx *c = nullptr;
+                check(zg_ctx_create(devices[i], &c)); // a context of its own per shard: shards run concurrently
+                ctxs_.push_back(c);
+                zg_bases *b = nullptr;
+                check(zg_bases_create(c, ppT::curve_id, GroupT::group_id, gs.data() + lo, hi - lo, ZG_FORM_PLAIN, ZG_MEM_HOST, &b));
+                shards_.push_back(b);
+                first_.push_back(lo);
+            }
+        } catch (...) {
+            release(); // a constructor that throws runs no destructor: give back what the earlier shards hold
+            throw;
         }
         first_.push_back(n);
     }
-    ~sharded_bases()
-    {
-        for (zg_bases *b : shards_) {
-            zg_bases_free(b);
-        }
-        for (zg_ctx *c : ctxs_) {
-            zg_ctx_destroy(c);
-        }
-    }
+    ~sharded_bases() { release(); }
     sharded_bases(const sharded_bases &) = delete;
     sharded_bases &operator=(const sharded_bases &) = delete;
     void precompute(int window_bits = 0)
@@ -595,6 +796,17 @@ public:
     }
 
 private:
+    void release()
+    {
+        for (zg_bases *b : shards_) {
+            zg_bases_free(b);
+        }
+        for (zg_ctx *c : ctxs_) {
+            zg_ctx_destroy(c);
+        }
+        shards_.clear();
+        ctxs_.clear();
+    }
     std::vector<zg_ctx *> ctxs_;
     std::vector<zg_bases *> shards_;
     std::vector<size_t> first_;

@@ -239,6 +239,48 @@ template<typename kcvectorT> void knowledge_commitment_vector_read_bytes(kcvecto
     }
 }
 
+/// sparse_vector / accumulation_vector of group elements (stream_utils.tcc:92-139)
+template<typename GroupT> void sparse_vector_write_bytes(const sparse_vector<GroupT> &v, std::ostream &out_s)
+{
+    const size_t num_entries = v.indices.size();
+    if (num_entries != v.values.size()) {
+        throw std::invalid_argument("sparse vector: indices / values size mismatch");
+    }
+    write_bytes(v.domain_size_, out_s);
+    write_bytes(num_entries, out_s);
+    for (size_t i = 0; i < num_entries; ++i) {
+        write_bytes(v.indices[i], out_s);
+        group_element_write_bytes(v.values[i], out_s);
+    }
+}
+
+template<typename GroupT> void sparse_vector_read_bytes(sparse_vector<GroupT> &v, std::istream &in_s)
+{
+    v.domain_size_ = read_bytes<size_t>(in_s);
+    const size_t num_entries = read_bytes<size_t>(in_s);
+    v.indices.clear();
+    v.values.clear();
+    v.indices.reserve(num_entries < internal::max_reserve ? num_entries : internal::max_reserve);
+    v.values.reserve(num_entries < internal::max_reserve ? num_entries : internal::max_reserve);
+    for (size_t i = 0; i < num_entries; ++i) {
+        v.indices.push_back(read_bytes<size_t>(in_s));
+        v.values.emplace_back();
+        group_element_read_bytes(v.values.back(), in_s);
+    }
+}
+
+template<typename GroupT> void accumulation_vector_write_bytes(const accumulation_vector<GroupT> &v, std::ostream &out_s)
+{
+    group_element_write_bytes(v.first, out_s);
+    sparse_vector_write_bytes(v.rest, out_s);
+}
+
+template<typename GroupT> void accumulation_vector_read_bytes(accumulation_vector<GroupT> &v, std::istream &in_s)
+{
+    group_element_read_bytes(v.first, in_s);
+    sparse_vector_read_bytes(v.rest, in_s);
+}
+
 // ---- r1cs (r1cs_serialization.tcc:199-275) ----
 template<typename FieldT> void linear_combination_read_bytes(linear_combination<FieldT> &lc, std::istream &in_s)
 {

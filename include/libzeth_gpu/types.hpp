@@ -15,6 +15,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../zeth_gpu.h"
@@ -172,6 +173,35 @@ template<typename FieldT> struct r1cs_constraint_system {
     size_t num_variables() const { return primary_input_size + auxiliary_input_size; }
     size_t num_constraints() const { return constraints.size(); }
     void add_constraint(const r1cs_constraint<FieldT> &c) { constraints.push_back(c); }
+    /// libsnark's r1cs_constraint_system::swap_AB_if_beneficial() [restated from the published libsnark source, which is
+    /// absent from /root/reference; the reference shows its use at libzeth/tests/mpc/groth16/mpc_test.cpp:42,164,340]:
+    /// when more variables occur in the B side of the constraints than in the A side, swap a and b in every constraint
+    /// (a * b = c is symmetric), so that the B query -- evaluated in G2 AND G1 -- is the sparser one.
+    /// Returns whether the sides were swapped.
+    bool swap_AB_if_beneficial()
+    {
+        std::vector<bool> touched_by_A(num_variables() + 1, false), touched_by_B(num_variables() + 1, false);
+        for (const r1cs_constraint<FieldT> &c : constraints) {
+            for (const linear_term<FieldT> &t : c.a.terms) {
+                touched_by_A.at(t.index) = true;
+            }
+            for (const linear_term<FieldT> &t : c.b.terms) {
+                touched_by_B.at(t.index) = true;
+            }
+        }
+        size_t non_zero_A_count = 0, non_zero_B_count = 0;
+        for (size_t i = 0; i < num_variables() + 1; ++i) {
+            non_zero_A_count += touched_by_A[i] ? 1 : 0;
+            non_zero_B_count += touched_by_B[i] ? 1 : 0;
+        }
+        if (non_zero_B_count <= non_zero_A_count) {
+            return false;
+        }
+        for (r1cs_constraint<FieldT> &c : constraints) {
+            std::swap(c.a, c.b);
+        }
+        return true;
+    }
 };
 
 template<typename FieldT> using r1cs_primary_input = std::vector<FieldT>;
@@ -213,6 +243,24 @@ template<typename T1, typename T2> struct knowledge_commitment {
 
 template<typename T1, typename T2> using knowledge_commitment_vector = sparse_vector<knowledge_commitment<T1, T2>>;
 
+/// libsnark::accumulation_vector<T>: `first` plus a sparse `rest` (the reference reads both members:
+/// groth16_snark.tcc:62-72, 216-224; stream_utils.tcc:125-139)
+template<typename T> struct accumulation_vector {
+    T first;
+    sparse_vector<T> rest;
+    accumulation_vector() : first(T::zero()) {}
+    /// first = v[0], rest = v[1..] at indices 0..n-2 (libsnark's accumulation_vector(first, std::vector rest))
+    explicit accumulation_vector(const std::vector<T> &v) : first(v.empty() ? T::zero() : v[0])
+    {
+        for (size_t i = 1; i < v.size(); i++) {
+            rest.indices.push_back(i - 1);
+            rest.values.push_back(v[i]);
+        }
+        rest.domain_size_ = rest.values.size();
+    }
+    size_t size() const { return rest.domain_size_ + 1; }
+};
+
 /// r1cs_gg_ppzksnark_proving_key<ppT> (fields as enumerated by groth16_snark.tcc:101-110)
 template<typename ppT> struct r1cs_gg_ppzksnark_proving_key {
     G1<ppT> alpha_g1;
@@ -225,6 +273,21 @@ template<typename ppT> struct r1cs_gg_ppzksnark_proving_key {
     G1_vector<ppT> H_query;
     G1_vector<ppT> L_query;
     r1cs_constraint_system<Fr<ppT>> constraint_system;
+};
+
+/// r1cs_gg_ppzksnark_verification_key<ppT> as this fork's verifier uses it (fields as read by groth16_snark.tcc:62-72,
+/// 86-90, 119-123; gamma is the G2 generator: SURVEY KAT-6)
+template<typename ppT> struct r1cs_gg_ppzksnark_verification_key {
+    G1<ppT> alpha_g1;
+    G2<ppT> beta_g2;
+    G2<ppT> delta_g2;
+    accumulation_vector<G1<ppT>> ABC_g1; // num_inputs + 1 entries
+};
+
+/// r1cs_gg_ppzksnark_keypair<ppT> (groth16_snark.hpp:20; groth16_snark.tcc:177-191)
+template<typename ppT> struct r1cs_gg_ppzksnark_keypair {
+    r1cs_gg_ppzksnark_proving_key<ppT> pk;
+    r1cs_gg_ppzksnark_verification_key<ppT> vk;
 };
 
 /// r1cs_gg_ppzksnark_proof<ppT> (groth16_snark.tcc:154-156, 163-165)

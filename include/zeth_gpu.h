@@ -149,12 +149,14 @@ int zg_runtime_info(char* buf, size_t cap, int* mixed);
 int zg_ntt(zg_ctx* ctx, int curve, void* data, unsigned log_n, int inverse, int coset, int form, int mem);
 
 /* zg_ntt on device memory (d_data: 2^log_n Fr elements in HBM, transformed in place) for callers that cannot allocate:
- * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * tight serving loops and harnesses that forbid hipMalloc.  No counterpart in the reference.
  * It calls no hipMalloc / hipFree / allocating routine: the domain's twiddle and coset tables and the transform buffer
  * live in a static device array of 4,254,720 bytes that every GPU the library runs on holds until the process ends.
- * Limit: log_n <= 16 (ZG_ERR_UNSUPPORTED beyond).  All calls on one GPU share that array (whatever their context), so
- * calls that overlap on one GPU race; the array keeps the last call's tables and rebuilds them, with kernels only, when
- * another (curve, log_n) is asked for.  Results are those of zg_ntt. */
+ * Limit: log_n <= 16 (ZG_ERR_UNSUPPORTED beyond).  Like zg_ntt it runs on the context's own stream and returns when the
+ * result is in d_data (it ends in a stream synchronisation), so it is NOT a call to place inside a HIP graph capture.
+ * All calls on one GPU share that array (whatever their context): the library makes them take turns (a per-GPU lock
+ * held for the whole call), keeps the last call's tables and rebuilds them, with kernels only, when another
+ * (curve, log_n) is asked for.  Results are those of zg_ntt. */
 int zg_ntt_noalloc(zg_ctx* ctx, int curve, void* d_data, unsigned log_n, int inverse, int coset, int form);
 
 /* One R1CS matrix in CSR form: row i (constraint i) holds the terms of its linear combination, `col` = variable

@@ -823,6 +823,64 @@ def proving_key_to_bytes(curve: Curve, pk: "ProvingKey") -> bytes:
     return out + r1cs_to_bytes(curve, pk.cs)
 
 
+def verification_key_to_bytes(curve: Curve, vk: "VerificationKey") -> bytes:
+    """groth16_snark.tcc:76-91: alpha_g1, beta_g2, delta_g2, then ABC_g1 as libsnark's accumulation_vector: the first
+    element, then the rest as a sparse vector (domain size, entry count, (index, value) pairs; indices 0..n-1) --
+    stream_utils.tcc:110-139."""
+    rest = vk.ABC_g1[1:]
+    out = g1_to_bytes(curve, vk.alpha_g1) + g2_to_bytes(curve, vk.beta_g2) + g2_to_bytes(curve, vk.delta_g2)
+    out += g1_to_bytes(curve, vk.ABC_g1[0]) + _u64(len(rest)) + _u64(len(rest))
+    for i, P in enumerate(rest):
+        out += _u64(i) + g1_to_bytes(curve, P)
+    return out
+
+
+def verification_key_from_bytes(curve: Curve, raw: bytes) -> "VerificationKey":
+    """groth16_snark.tcc:113-128 (the well-formedness check is the caller's)."""
+    n1, n2 = 2 * curve.fq_bytes, 4 * curve.fq_bytes
+    vk = VerificationKey()
+    vk.alpha_g1 = g1_from_bytes(curve, raw[:n1])
+    vk.beta_g2 = g2_from_bytes(curve, raw[n1 : n1 + n2])
+    vk.delta_g2 = g2_from_bytes(curve, raw[n1 + n2 : n1 + 2 * n2])
+    pos = n1 + 2 * n2
+    vk.ABC_g1 = [g1_from_bytes(curve, raw[pos : pos + n1])]
+    count = int.from_bytes(raw[pos + n1 + 8 : pos + n1 + 16], "little")
+    pos += n1 + 16
+    for i in range(count):
+        assert int.from_bytes(raw[pos : pos + 8], "little") == i
+        vk.ABC_g1.append(g1_from_bytes(curve, raw[pos + 8 : pos + 8 + n1]))
+        pos += 8 + n1
+    assert pos == len(raw)
+    return vk
+
+
+def verification_key_to_json(curve: Curve, vk: "VerificationKey") -> str:
+    """groth16_snark.tcc:58-74."""
+    out = '{\n  "alpha": %s,\n  "beta": %s,\n  "delta": %s,\n  "ABC": [\n    %s' % (
+        g1_to_json(curve, vk.alpha_g1), g2_to_json(curve, vk.beta_g2), g2_to_json(curve, vk.delta_g2), g1_to_json(curve, vk.ABC_g1[0]))
+    for P in vk.ABC_g1[1:]:
+        out += ",\n    " + g1_to_json(curve, P)
+    return out + "\n  ]\n}"
+
+
+def keypair_to_bytes(curve: Curve, pk: "ProvingKey", vk: "VerificationKey") -> bytes:
+    """groth16_snark.tcc:177-183: the proving key, then the verification key (prover_server's keypair.bin)."""
+    return proving_key_to_bytes(curve, pk) + verification_key_to_bytes(curve, vk)
+
+
+def swap_AB_if_beneficial(cs: "R1CS") -> "R1CS":
+    """libsnark r1cs_constraint_system::swap_AB_if_beneficial (restated from the published libsnark source; used by the
+    reference at libzeth/tests/mpc/groth16/mpc_test.cpp:42,164,340): swap a and b everywhere when B touches more
+    variables than A."""
+    touched_a, touched_b = set(), set()
+    for a, b, _ in cs.constraints:
+        touched_a.update(dict(a).keys() if not isinstance(a, dict) else a.keys())
+        touched_b.update(dict(b).keys() if not isinstance(b, dict) else b.keys())
+    if len(touched_b) <= len(touched_a):
+        return cs
+    return R1CS(cs.num_inputs, cs.num_aux, [(b, a, c) for a, b, c in cs.constraints])
+
+
 def proof_to_bytes(curve: Curve, proof) -> bytes:
     g_A, g_B, g_C = proof
     return g1_to_bytes(curve, g_A) + g2_to_bytes(curve, g_B) + g1_to_bytes(curve, g_C)

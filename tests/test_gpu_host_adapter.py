@@ -109,34 +109,8 @@ def test_adapter_generate_proof_from_protoboard_as_first_call(curve, tmp_path):
     assert M.verify(C, vk2, primary, M.proof_from_bytes(C, p3))
 
 
-def vk_to_bytes(C, vk):
-    """groth16_snark::verification_key_write_bytes (groth16_snark.tcc:77-91): ABC_g1 as libsnark's accumulation_vector,
-    first element then the rest as a sparse vector with indices 0..n-1 (stream_utils.tcc:111-139)."""
-    u64 = lambda x: x.to_bytes(8, "little")  # noqa: E731
-    rest = vk.ABC_g1[1:]
-    out = M.g1_to_bytes(C, vk.alpha_g1) + M.g2_to_bytes(C, vk.beta_g2) + M.g2_to_bytes(C, vk.delta_g2) + M.g1_to_bytes(C, vk.ABC_g1[0])
-    out += u64(len(rest)) + u64(len(rest))
-    for i, P in enumerate(rest):
-        out += u64(i) + M.g1_to_bytes(C, P)
-    return out
-
-
-def vk_from_bytes(C, raw):
-    n1, n2 = 2 * C.fq_bytes, 4 * C.fq_bytes
-    vk = M.VerificationKey()
-    vk.alpha_g1 = M.g1_from_bytes(C, raw[:n1])
-    vk.beta_g2 = M.g2_from_bytes(C, raw[n1:n1 + n2])
-    vk.delta_g2 = M.g2_from_bytes(C, raw[n1 + n2:n1 + 2 * n2])
-    pos = n1 + 2 * n2
-    vk.ABC_g1 = [M.g1_from_bytes(C, raw[pos:pos + n1])]
-    count = int.from_bytes(raw[pos + n1 + 8:pos + n1 + 16], "little")
-    pos += n1 + 16
-    for i in range(count):
-        assert int.from_bytes(raw[pos:pos + 8], "little") == i
-        vk.ABC_g1.append(M.g1_from_bytes(C, raw[pos + 8:pos + 8 + n1]))
-        pos += 8 + n1
-    assert pos == len(raw)
-    return vk
+vk_to_bytes = lambda C, vk: M.verification_key_to_bytes(C, vk)  # noqa: E731
+vk_from_bytes = M.verification_key_from_bytes
 
 
 @pytest.mark.parametrize("curve", sorted(CURVES))
@@ -156,6 +130,7 @@ def test_adapter_generator_from_secrets_and_generate_setup(curve, tmp_path):
         tmp_path / "proof", tmp_path / "asg", len(primary))
     assert (tmp_path / "pk").read_bytes() == M.proving_key_to_bytes(C, pk)
     assert (tmp_path / "vk").read_bytes() == vk_to_bytes(C, vk)
+    assert (tmp_path / "pk.keypair").read_bytes() == M.keypair_to_bytes(C, pk, vk)  # keypair_write_bytes (groth16_snark.tcc:177-183)
     fresh_vk = vk_from_bytes(C, (tmp_path / "vk.fresh").read_bytes())
     assert fresh_vk.alpha_g1 != vk.alpha_g1
     proof = M.proof_from_bytes(C, (tmp_path / "proof").read_bytes())
@@ -205,7 +180,7 @@ def test_adapter_multi_exp_sharded(curve, group, shards, tmp_path):
 
 
 def test_adapter_proving_key_pool(tmp_path):
-    """device_proving_key_pool: one resident key per device, provers handed out round-robin (here two copies on device 0)."""
+    """device_proving_key_pool over two devices' worth of resident keys (here two copies on device 0, one prover each)."""
     C = CURVES["alt-bn128"]
     cs, pk, vk, primary, aux = simple_instance(C, [7, 9])
     (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
@@ -214,6 +189,56 @@ def test_adapter_proving_key_pool(tmp_path):
     run(DRIVER, "prove_pool", "alt-bn128", tmp_path / "pk", tmp_path / "asg", 1, "%x" % r, "%x" % s, tmp_path / "a", tmp_path / "b")
     want = M.proof_to_bytes(C, M.prove(C, pk, primary, aux, r, s))
     assert (tmp_path / "a").read_bytes() == want and (tmp_path / "b").read_bytes() == want
+
+
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_adapter_proofs_in_flight_through_the_pool(curve, tmp_path):
+    """BASELINE configs[4] as prover_server would bind it (prover_server.cpp:118-201: concurrent handlers, one shared
+    keypair): four threads prove through ONE device_proving_key_pool (device 0, four provers = the uploaded key and three
+    zg_pk_clone clones created on demand).  Every proof is byte-equal to the oracle's for its own (r, s); the proofs
+    overlap (peak in flight > 1); the stateless generate_proof called from the same four threads at once gives valid
+    proofs as well."""
+    C = CURVES[curve]
+    cs, pk, vk, primary, aux = simple_instance(C, [3, 5, 7])
+    (tmp_path / "pk").write_bytes(M.proving_key_to_bytes(C, pk))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    r, s = 0x1F2E3D4C5B6A7988, 0x123456789ABCDEF012345
+    threads, per = 4, 6
+    out = run(DRIVER, "prove_concurrent", curve, tmp_path / "pk", tmp_path / "asg", 1, "%x" % r, "%x" % s, threads, per, tmp_path / "p")
+    words = out.stdout.split()
+    peak, done = int(words[words.index("peak_in_flight") + 1]), int(words[words.index("proofs") + 1])
+    assert done == threads * per and 2 <= peak <= 4, out.stdout
+    for k in range(threads * per):
+        want = M.proof_to_bytes(C, M.prove(C, pk, primary, aux, r + k, s + 2 * k + 1))
+        assert (tmp_path / ("p.%d" % k)).read_bytes() == want, "proof %d" % k
+    seen = set()
+    for t in range(threads):
+        raw = (tmp_path / ("p.s%d" % t)).read_bytes()
+        assert M.verify(C, vk, primary, M.proof_from_bytes(C, raw))
+        seen.add(raw)
+    assert len(seen) == threads
+
+
+def test_generate_setup_swaps_a_and_b_when_beneficial(tmp_path):
+    """r1cs_gg_ppzksnark_generator on a system whose B side touches more variables than its A side: the key is built
+    for the swapped system (swap_AB_if_beneficial) and its proof verifies under its own verification key."""
+    C = BN254
+    cs = M.simple_circuit(C, 2)
+    flipped = M.R1CS(cs.num_inputs, cs.num_aux, [(b, a, c) for a, b, c in cs.constraints])
+    # one of the two orientations is the one the generator swaps
+    swapped = [M.swap_AB_if_beneficial(x) is not x for x in (cs, flipped)]
+    assert swapped.count(True) == 1
+    target = flipped if swapped[1] else cs
+    primary, aux = M.simple_circuit_assignment(C, [10, 12])
+    (tmp_path / "r1cs").write_bytes(M.r1cs_to_bytes(C, target))
+    (tmp_path / "asg").write_bytes(M.assignment_to_bytes(C, primary + aux))
+    run(DRIVER, "setup", "alt-bn128", tmp_path / "r1cs", "1234567abcdef", "2345678", "3456789", "456789a0f", tmp_path / "pk", tmp_path / "vk",
+        tmp_path / "proof", tmp_path / "asg", len(primary))
+    fresh_vk = vk_from_bytes(C, (tmp_path / "vk.fresh").read_bytes())
+    assert M.verify(C, fresh_vk, primary, M.proof_from_bytes(C, (tmp_path / "proof").read_bytes()))
+    # the from-secrets form does not swap (mpc_test.cpp:340 applies the swap itself before comparing)
+    pk, vk = M.generator_from_secrets(C, target, 0x1234567ABCDEF, 0x2345678, 0x3456789, 0x456789A0F)
+    assert (tmp_path / "pk").read_bytes() == M.proving_key_to_bytes(C, pk)
 
 
 @pytest.mark.parametrize("curve", sorted(CURVES))

@@ -199,13 +199,16 @@ def generator_from_secrets_fast(C, cs, rng):
     return pk, None
 
 
-def test_failed_prove_is_followed_by_a_correct_proof(ctx, monkeypatch):
-    """An error after the lanes were queued (forced through the library's test hook) drains every stream before it is
-    returned: the next zg_prove on the same key gives the oracle's proof."""
+def _failed_prove_body():
+    """Runs in a process of its own (below) against the -DZG_DEBUG_KNOBS build, whose ZG_TEST_FAIL_LANE hook makes the
+    queueing of one lane (0-3) or of the H chain (4) report a failure after the other streams were queued."""
+    import os
+
     import zeth_amd
 
     C = BN254
     rng = random.Random(99)
+    ctx = zeth_amd.Context(0)
     cs, primary, aux = random_r1cs(C, rng, 2, 900, 1500)
     pk, _ = generator_from_secrets_fast(C, cs, rng)
     dpk = zeth_amd.ProvingKey.from_model(ctx, 0, pk, C.r)
@@ -213,10 +216,47 @@ def test_failed_prove_is_followed_by_a_correct_proof(ctx, monkeypatch):
     want = cpu_oracle.prove(0, C, pk, primary, aux, 5, 7, chunks=2)
     assert snark.generate_proof(dpk, primary, aux, 5, 7) == want
     for lane in ("0", "2", "4"):
-        monkeypatch.setenv("ZG_TEST_FAIL_LANE", lane)
-        with pytest.raises(zeth_amd.ZethGpuError) as e:
+        os.environ["ZG_TEST_FAIL_LANE"] = lane
+        try:
             snark.generate_proof(dpk, primary, aux, 5, 7)
-        assert e.value.status == -4
-        monkeypatch.delenv("ZG_TEST_FAIL_LANE")
+        except zeth_amd.ZethGpuError as e:
+            assert e.status == -4
+        else:
+            raise AssertionError("the injected failure of lane %s was not reported" % lane)
+        del os.environ["ZG_TEST_FAIL_LANE"]
         assert snark.generate_proof(dpk, primary, aux, 5, 7) == want
+    dpk.free()
+    ctx.close()
+    print("failed-prove ok")
+
+
+def test_failed_prove_is_followed_by_a_correct_proof():
+    """An error after the lanes were queued drains every stream before it is returned: the next zg_prove on the same key
+    gives the oracle's proof.  The failure is injected through a hook that only the debug build of the library has
+    (build/dbg/libzeth_gpu.so, `make dbg`); the shipped library ignores the variable, which is checked too."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "build", "dbg", "libzeth_gpu.so")
+    assert os.path.exists(dbg), "build/dbg/libzeth_gpu.so is missing: run `make dbg`"
+    code = "import sys; sys.path[:0] = [%r, %r, %r]; import test_gpu_prover as T; T._failed_prove_body()" % (
+        root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
+    env = dict(os.environ, ZETH_GPU_LIBRARY=dbg)
+    env.pop("ZG_TEST_FAIL_LANE", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110, env=env)
+    assert p.returncode == 0 and "failed-prove ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_shipped_library_ignores_the_fault_injection_knob(ctx, monkeypatch):
+    import zeth_amd
+
+    C = BN254
+    cs = simple_circuit(C, 2)
+    pk, vk = generator_from_secrets(C, cs, 11, 12, 13, 14)
+    primary, aux = simple_circuit_assignment(C, [3, 4])
+    dpk = zeth_amd.ProvingKey.from_model(ctx, 0, pk, C.r)
+    monkeypatch.setenv("ZG_TEST_FAIL_LANE", "0")
+    assert zeth_amd.Groth16Snark(ctx, 0).generate_proof(dpk, primary, aux, 5, 7) == prove(C, pk, primary, aux, 5, 7)
     dpk.free()

@@ -88,6 +88,55 @@ def test_proving_key_and_assignment_round_trip(curve, tmp_path):
     assert (tmp_path / "asg2").read_bytes() == asg_bytes
 
 
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_keypair_file_written_by_the_oracle_is_read_by_the_host_module(curve, tmp_path):
+    """keypair_read_bytes / keypair_write_bytes / verification_key_{read,write}_bytes / verification_key_write_json
+    (groth16_snark.tcc:58-91, 113-128, 177-191): prover_server loads ~/zeth_setup/keypair.bin with exactly these
+    (prover_server.cpp:456-463, 487-490).  The file is written by the oracle's codec and every writer's output is
+    compared with it."""
+    C = CURVES[curve]
+    cs, pk, vk = simple_key(C, 2)
+    kp_bytes = M.keypair_to_bytes(C, pk, vk)
+    (tmp_path / "kp").write_bytes(kp_bytes)
+    out = run(DRIVER, "keypair", curve, tmp_path / "kp", tmp_path / "pk", tmp_path / "vk", tmp_path / "vk.json", tmp_path / "kp2")
+    assert "%d A, %d ABC" % (cs.num_variables + 1, cs.num_inputs + 1) in out.stdout
+    assert (tmp_path / "pk").read_bytes() == M.proving_key_to_bytes(C, pk)
+    assert (tmp_path / "vk").read_bytes() == M.verification_key_to_bytes(C, vk)
+    assert (tmp_path / "kp2").read_bytes() == kp_bytes
+    assert (tmp_path / "vk.json").read_text() == M.verification_key_to_json(C, vk)
+    back = M.verification_key_from_bytes(C, (tmp_path / "vk").read_bytes())
+    assert back.ABC_g1 == vk.ABC_g1 and back.alpha_g1 == vk.alpha_g1
+    # a verification key that is not well-formed: std::invalid_argument (groth16_snark.tcc:125-127)
+    bad = bytearray(kp_bytes)
+    bad[-1] ^= 1  # low byte of the last ABC point's Y
+    (tmp_path / "bad").write_bytes(bytes(bad))
+    assert "verification key (read) not well-formed" in run(
+        DRIVER, "keypair", curve, tmp_path / "bad", tmp_path / "o1", tmp_path / "o2", tmp_path / "o3", tmp_path / "o4", expect=10).stderr
+    # the file cut inside the verification key: a stream failure
+    (tmp_path / "cut").write_bytes(kp_bytes[:-40])
+    run(DRIVER, "keypair", curve, tmp_path / "cut", tmp_path / "o1", tmp_path / "o2", tmp_path / "o3", tmp_path / "o4", expect=12)
+
+
+def test_swap_AB_if_beneficial(tmp_path):
+    """r1cs_gg_ppzksnark_generator works on a copy of the system with swap_AB_if_beneficial() applied (the reference's
+    callers of the from-secrets form apply it themselves: mpc_test.cpp:42,164,340): a and b change places exactly when
+    B touches more variables than A."""
+    C = BN254
+    # B touches 4 variables, A touches 2: swapped
+    dense_b = R1CS(1, 4, [({1: 1}, {2: 1, 3: 1}, {4: 1}), ({1: 2}, {4: 1, 5: 3}, {2: 1}), ({2: 1}, {3: 1}, {5: 1})])
+    (tmp_path / "in").write_bytes(M.r1cs_to_bytes(C, dense_b))
+    assert run(DRIVER, "swap_ab", "alt-bn128", tmp_path / "in", tmp_path / "out").stdout.strip() == "swapped"
+    want = M.swap_AB_if_beneficial(dense_b)
+    assert want is not dense_b and (tmp_path / "out").read_bytes() == M.r1cs_to_bytes(C, want)
+    # the swapped system is left alone (A now touches more), and so is a tie
+    (tmp_path / "in2").write_bytes(M.r1cs_to_bytes(C, want))
+    assert run(DRIVER, "swap_ab", "alt-bn128", tmp_path / "in2", tmp_path / "out2").stdout.strip() == "kept"
+    assert (tmp_path / "out2").read_bytes() == M.r1cs_to_bytes(C, want)
+    tie = R1CS(1, 2, [({1: 1}, {2: 1}, {3: 1})])
+    (tmp_path / "in3").write_bytes(M.r1cs_to_bytes(C, tie))
+    assert run(DRIVER, "swap_ab", "alt-bn128", tmp_path / "in3", tmp_path / "out3").stdout.strip() == "kept"
+
+
 def test_identity_is_written_as_zero_one(tmp_path):
     """group_element_utils.tcc:93-113: the identity travels as (0, 1); a key whose B_query holds one survives."""
     C = BN254

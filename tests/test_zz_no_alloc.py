@@ -75,3 +75,44 @@ def test_noalloc_ntt_matches_cpu_oracle_and_rejects_large():
         big.free()
     finally:
         ctx.close()
+
+
+def test_noalloc_ntt_from_two_contexts_at_once():
+    """Two contexts on one GPU (the serving-loop case) call the entry point from two threads with different domains: the
+    calls share the GPU's static scratch, so the library makes them take turns -- every result equals zg_ntt's."""
+    import threading
+
+    import zeth_amd
+    from zeth_amd.synth import random_scalars_host
+
+    cid, C = CURVES["alt-bn128"]
+    errors = []
+
+    def worker(k):
+        ctx = zeth_amd.Context(0)
+        try:
+            for it in range(6):
+                log_m = (9, 12)[(k + it) % 2] if it % 3 else (14, 11)[k]
+                m = 1 << log_m
+                host = random_scalars_host(m, C.r, seed=100 * k + it).tobytes()
+                dom = zeth_amd.EvaluationDomain(ctx, cid, m)
+                inverse, coset = VARIANTS[(k + it) % 4]
+                want = zeth_amd.DeviceBuffer.from_bytes(ctx, host)
+                dom._run(want, inverse, coset)
+                got = zeth_amd.DeviceBuffer.from_bytes(ctx, host)
+                dom.run_noalloc(got, inverse, coset)
+                if got.download() != want.download():
+                    errors.append((k, it, log_m))
+                want.free()
+                got.free()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            ctx.close()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

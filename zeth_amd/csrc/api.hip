@@ -27,7 +27,8 @@ struct StaticScratch {
   unsigned tag_log_m = 0;
 };
 static StaticScratch g_static[ZG_MAX_DEVICES];
-static std::mutex g_static_mu;
+static std::mutex g_static_mu;                       // guards the resolution of `ptr`
+static std::mutex g_static_call_mu[ZG_MAX_DEVICES];  // one zg_ntt_noalloc at a time per GPU: the scratch and its tags are shared
 
 // with `device` current: resolve the device address of `scratch` once per device
 static int static_scratch_resolve(int device) {
@@ -438,6 +439,9 @@ int zg_ntt_noalloc(zg_ctx* ctx, int curve, void* d_data, unsigned log_n, int inv
   if (ctx->device < 0 || ctx->device >= ZG_MAX_DEVICES) return ZG_ERR_UNSUPPORTED;
   if (ops->ntt_static_bytes() > ZG_STATIC_SCRATCH_BYTES) return ZG_ERR_UNSUPPORTED;
   ZG_HIP(hipSetDevice(ctx->device));
+  // The call is synchronous, so holding the device's lock for all of it costs nothing and makes calls from several
+  // contexts on one GPU (the serving-loop case) take turns on the shared scratch instead of racing on it.
+  std::lock_guard<std::mutex> lock(g_static_call_mu[ctx->device]);
   StaticScratch& sc = g_static[ctx->device];  // ptr was resolved when this context was created
   if (!sc.ptr) return ZG_ERR_HIP;
   return ops->ntt_static(ctx, curve, d_data, log_n, inverse != 0, coset != 0, form, sc.ptr, ZG_STATIC_SCRATCH_BYTES,
@@ -514,6 +518,15 @@ int zg_witness_map(zg_pk* pk, const void* primary, size_t n_primary, const void*
   ZG_HIP(hipSetDevice(pk->ctx->device));
   return pk->impl->witness_map_out(primary, n_primary, aux, n_aux, form, out_form, h_out);
 }
+
+#ifdef ZG_DEBUG_KNOBS
+int zg_debug_pk_progress(zg_pk* pk, char* buf, size_t cap) {
+  if (!pk || !buf || !cap) return ZG_ERR_INVALID_ARGUMENT;
+  const std::string s = pk->impl->debug_progress();
+  snprintf(buf, cap, "%s", s.c_str());
+  return ZG_OK;
+}
+#endif
 
 int zg_host_group_op(int curve, int group, int op, const void* a, const void* b, int form, void* out) {
   const GroupOps* ops = zg_group_ops(curve, group);

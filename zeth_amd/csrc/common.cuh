@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/zeth_gpu.h"
+#include "knobs.h"
 
 #define ZG_HIP(expr)                                                                                   \
   do {                                                                                                 \
@@ -173,6 +175,11 @@ struct PkBase {
                               int out_form, void* h_out) = 0;
   virtual size_t domain_size() const = 0;
   virtual int clone_onto(zg_ctx* ctx, PkBase** out) const = 0;
+#ifdef ZG_DEBUG_KNOBS
+  // which of the proof's streams have drained and how far each got (phase marks); callable from a watchdog thread while
+  // zg_prove is blocked (tools/diag_prio.py)
+  virtual std::string debug_progress() const = 0;
+#endif
 };
 
 struct zg_pk {

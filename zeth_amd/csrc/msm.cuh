@@ -31,6 +31,7 @@
 #include "curve.cuh"
 #include "curve_quad.cuh"
 #include "curve_quad29.cuh"
+#include "knobs.h"
 
 namespace zg {
 
@@ -119,7 +120,7 @@ inline void msm_cap_segments(MsmPlan& p) {
   // of a segment (2 k additions + the weighting) is the latency of the whole reduction then
   // (measurement knob: with few windows or groups, more and shorter segments up to this many quads -- inside a proof it
   // made no difference: c = 17, 2048 / 4096 / 8192 segments a group 384 / 388 / 388 proofs/s)
-  if (const char* e = getenv("ZG_MSM_MORE_SEGMENTS")) {
+  if (const char* e = zg_knob("ZG_MSM_MORE_SEGMENTS")) {
     const size_t lim = strtoul(e, nullptr, 0);
     while (p.T < p.nb / 4 && (size_t)p.T * (size_t)p.W * 2 <= lim) p.T <<= 1;
   }
@@ -141,7 +142,7 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   size_t L = ((size_t)p.W * n) >> 18;
   if (L < 32) L = 32;
   if (L > 1024) L = 1024;
-  if (const char* e = getenv("ZG_MSM_UNIT_LEN")) {  // tuning knob
+  if (const char* e = zg_knob("ZG_MSM_UNIT_LEN")) {  // tuning knob
     size_t v = strtoul(e, nullptr, 0);
     if (v >= 1 && v <= 1024) L = v;
   }
@@ -157,7 +158,7 @@ inline MsmPlan msm_make_plan(size_t n, int scalar_bits, int force_c = 0) {
   // reduce2 then folds the T segment sums of a window; measured best: 1024 segments up to 2^14 buckets, 2048 above
   p.T = p.nb < 1024 ? p.nb : (p.nb >= 32768 ? 2048 : 1024);
   msm_cap_segments(p);
-  if (const char* e = getenv("ZG_MSM_SEGMENTS")) {  // tuning knob (power of two)
+  if (const char* e = zg_knob("ZG_MSM_SEGMENTS")) {  // tuning knob (power of two)
     uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
     if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) p.T = v;
   }
@@ -190,7 +191,7 @@ inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
   if (L < load4) L = load4;
   if (L < 32) L = 32;
   if (L > 1024) L = 1024;
-  if (const char* e = getenv("ZG_MSM_UNIT_LEN")) {
+  if (const char* e = zg_knob("ZG_MSM_UNIT_LEN")) {
     size_t v = strtoul(e, nullptr, 0);
     if (v >= 1 && v <= 1024) L = v;
   }
@@ -206,7 +207,7 @@ inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
   p.nchunk = nchunk;
   p.T = p.nb < 1024 ? p.nb : (p.nb >= 32768 ? 2048 : 1024);
   msm_cap_segments(p);
-  if (const char* e = getenv("ZG_MSM_SEGMENTS")) {
+  if (const char* e = zg_knob("ZG_MSM_SEGMENTS")) {
     uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
     if (v >= 1 && v <= p.nb && (v & (v - 1)) == 0) p.T = v;
   }

@@ -293,7 +293,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   // for the plain sequence -- the sort's 1024-lane workgroups displace accumulation waves for longer than the sort
   // takes on its own (k_accum 25.1 -> 31.6 ms), so the sequence stays sort-then-accumulate.
   const uint32_t Wn = (uint32_t)p.W;
-  const bool split = !tab && nhi && Wn >= 8 && n >= ((size_t)1 << 21) && getenv("ZG_MSM_SPLIT");
+  const bool split = !tab && nhi && Wn >= 8 && n >= ((size_t)1 << 21) && zg_knob("ZG_MSM_SPLIT");
   const uint32_t g0 = split ? (Wn + 3) / 4 : Wn;  // windows [Wn - g0, Wn) form the first group
   const uint32_t w_lo = Wn - g0;
   if (split) ZG_TRY(ctx->side_init());

@@ -44,7 +44,7 @@ inline Fr host_pow_u64(Fr b, uint64_t e) {
 // knob).
 inline uint32_t ntt_tile_elems() {
   static const uint32_t v = [] {
-    const char* e = getenv("ZG_NTT_TILE_ELEMS");
+    const char* e = zg_knob("ZG_NTT_TILE_ELEMS");
     const uint32_t x = e ? (uint32_t)atoi(e) : 0u;
     return (x == 2048u || x == 4096u) ? x : 2048u;
   }();
@@ -238,7 +238,7 @@ int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, 
 // few lanes), radix 8 never (150 VGPRs, half the waves).  ZG_NTT_RADIX_LOG = 1 | 2 overrides (tuning knob).
 inline int ntt_pick_rmax(size_t total_elems) {
   static const int forced = [] {
-    const char* e = getenv("ZG_NTT_RADIX_LOG");
+    const char* e = zg_knob("ZG_NTT_RADIX_LOG");
     return e ? atoi(e) : 0;
   }();
   if (forced >= 1 && forced <= 2) return forced;
@@ -297,10 +297,8 @@ int ntt_static(zg_ctx* ctx, int curve, void* d_data, unsigned log_m, int inverse
   Fr* tmp = tables + ntt_static_table_elems();
   NttDomain<Fr> D;  // storage stays null: nothing to free
   const bool cached = *tag_curve == curve && *tag_log_m == log_m;
-  *tag_curve = -1;  // nothing valid until the fill has been queued without error
+  *tag_curve = -1;  // nothing valid until the fill kernels are KNOWN to have run (set again after the synchronise below)
   ZG_TRY(ntt_fill_tables<Fr>(ctx, log_m, tables, &D, !cached));
-  *tag_curve = curve;
-  *tag_log_m = log_m;
   const size_t m = (size_t)1 << log_m;
   Fr* data = reinterpret_cast<Fr*>(d_data);
   hipStream_t st = ctx->stream;
@@ -310,11 +308,14 @@ int ntt_static(zg_ctx* ctx, int curve, void* d_data, unsigned log_m, int inverse
   if (form == ZG_FORM_PLAIN) hipLaunchKernelGGL((k_fr_convert<Fr>), dim3(blocks), dim3(256), 0, st, data, m, 1);
   int s = ntt_launch<Fr>(ctx, &D, data, tmp, inverse, coset);
   ctx->profiling = prof;
+  if (s == ZG_OK && hipMemcpyAsync(data, tmp, m * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) s = ZG_ERR_HIP;
+  if (s == ZG_OK && form == ZG_FORM_PLAIN) hipLaunchKernelGGL((k_fr_convert<Fr>), dim3(blocks), dim3(256), 0, st, data, m, 0);
+  if (s == ZG_OK && hipGetLastError() != hipSuccess) s = ZG_ERR_HIP;
+  // whatever was queued is waited for even after an error: the scratch is shared and the next call may overwrite it
+  if (hipStreamSynchronize(st) != hipSuccess && s == ZG_OK) s = ZG_ERR_HIP;
   ZG_TRY(s);
-  ZG_HIP(hipMemcpyAsync(data, tmp, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-  if (form == ZG_FORM_PLAIN) hipLaunchKernelGGL((k_fr_convert<Fr>), dim3(blocks), dim3(256), 0, st, data, m, 0);
-  ZG_HIP(hipGetLastError());
-  ZG_HIP(hipStreamSynchronize(st));
+  *tag_curve = curve;
+  *tag_log_m = log_m;
   return ZG_OK;
 }
 

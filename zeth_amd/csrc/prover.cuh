@@ -209,7 +209,7 @@ struct ProvingKeyDev : PkBase {
       const size_t table_min = e ? strtoull(e, nullptr, 0) : ((size_t)1 << 18);
       if (table_min && v->H_len + 1 >= table_min && v->H_len >= 1024) {  // H_len = domain size - 1
         int c = 0, D = 0;
-        static const int h_table_c = getenv("ZG_PK_TABLE_C") ? atoi(getenv("ZG_PK_TABLE_C")) : 0;  // tuning knob
+        static const int h_table_c = zg_knob("ZG_PK_TABLE_C") ? atoi(zg_knob("ZG_PK_TABLE_C")) : 0;  // tuning knob
         // Up to 2^19 points a 17-bit table (15 digits, 2^16 buckets in two groups) instead of the lone evaluation's 20 bits:
         // alone the two take the same time, inside a proof the eight times smaller reduction leaves the device to the
         // other evaluations (JoinSplit shape, four proofs in flight: 375 -> 385-398 proofs/s, latency unchanged).  From
@@ -263,9 +263,14 @@ struct ProvingKeyDev : PkBase {
 
   // side streams and per-proof device scratch (everything a proof in flight writes)
   int alloc_scratch() {
+    // (debug builds: ZG_LANE_PRIO = 1 | 0 | -1 puts the lanes at the highest / default / lowest stream priority and
+    // ZG_LANE_PROFILE turns their phase marks on, for tools/diag_prio.py)
+    static const int lane_prio = zg_knob("ZG_LANE_PRIO") ? atoi(zg_knob("ZG_LANE_PRIO")) : +1;
     for (auto& l : lane) {
-      ZG_TRY(zg_ctx_create_prio(ctx->device, +1, &l));
+      ZG_TRY(zg_ctx_create_prio(ctx->device, lane_prio, &l));
       l->want_dense = true;
+      l->profiling = zg_knob("ZG_LANE_PROFILE") != nullptr;
+      if (zg_knob("ZG_LANE_PREALLOC_MB")) ZG_TRY(l->ws_reserve((size_t)atoi(zg_knob("ZG_LANE_PREALLOC_MB")) << 20));
       // The lanes' evaluations are off the proof's critical path (the H chain on the main stream): 128 bucket segments a
       // window instead of 1024 cut their reduction's instruction count 2.6x (profiles/r2_prove_valu_by_kernel.txt: the
       // reductions were 37 % of a proof's vector instructions), worth +10 % proofs/s with four proofs in flight.
@@ -362,7 +367,7 @@ struct ProvingKeyDev : PkBase {
 
   int prove_impl(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
                  const uint32_t* r_plain, const uint32_t* s_plain, int out_form, void* proof_out) {
-    const bool trace = getenv("ZG_PROVE_TRACE") != nullptr;
+    const bool trace = zg_knob("ZG_PROVE_TRACE") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
     auto stamp = [&](const char* what) {
       if (trace) fprintf(stderr, "  [prove] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
@@ -375,11 +380,17 @@ struct ProvingKeyDev : PkBase {
     // context with its own workspace) while the main stream computes H's coefficients and then the H evaluation.
     // ZG_PROVE_HOLD = 1 | 2 | 3 (measurement knob): the lanes start only after that many parts of the H chain's
     // transforms have run (0: as soon as 1||w is there)
-    static const int hold = getenv("ZG_PROVE_HOLD") ? atoi(getenv("ZG_PROVE_HOLD")) : 0;
+    static const int hold = zg_knob("ZG_PROVE_HOLD") ? atoi(zg_knob("ZG_PROVE_HOLD")) : 0;
     int h_status = ZG_OK;
     if (hold >= 1 && hold <= 3) h_status = qap_h(0, hold - 1);
     ZG_HIP(hipEventRecord(w_ready, st));
-    for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
+    // (debug builds: ZG_LANE_WAIT = 1 waits for 1||w on the host instead of in the lanes' queues)
+    static const int lane_wait = zg_knob("ZG_LANE_WAIT") ? atoi(zg_knob("ZG_LANE_WAIT")) : 0;
+    if (lane_wait == 1) {
+      ZG_HIP(hipEventSynchronize(w_ready));
+    } else {
+      for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
+    }
     const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
     const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
     XYZZ<Fq> At, Bt1, Ht, Lt;
@@ -391,8 +402,8 @@ struct ProvingKeyDev : PkBase {
     // the longest dependent chain (constraint evaluation, seven transforms, H evaluation) is queued by this thread on
     // the main stream; the side lanes run at the SAME stream priority (with the lowest priority they starved behind
     // the main stream's kernels: a proof did not finish in 100 s)
-    static const int h_c = getenv("ZG_PROVE_H_C") ? atoi(getenv("ZG_PROVE_H_C")) : 0;        // tuning knobs
-    static const int lane_c = getenv("ZG_PROVE_LANE_C") ? atoi(getenv("ZG_PROVE_LANE_C")) : 0;
+    static const int h_c = zg_knob("ZG_PROVE_H_C") ? atoi(zg_knob("ZG_PROVE_H_C")) : 0;        // tuning knobs
+    static const int lane_c = zg_knob("ZG_PROVE_LANE_C") ? atoi(zg_knob("ZG_PROVE_LANE_C")) : 0;
     // One bit narrower than a lone evaluation of that size would take (msm_pick_c): with five evaluations sharing the
     // device the reduction's chains count for more (JoinSplit shape, 44 K dense scalars: width 12 against 13 is 0.15-0.2 ms
     // of a proof; 11 and 14 are slower than either)
@@ -408,8 +419,8 @@ struct ProvingKeyDev : PkBase {
     // Few, long segments only while the evaluation is small: with 2^16 or more dense scalars the accumulation dwarfs the
     // reduction's instructions and its longer chain is what shows (BLS12-377, 2^20 constraints, 105 K dense scalars: 13.1 -> 12.2 ms with the
     // plan's own segment count).
-    static const int lane_t = getenv("ZG_PROVE_LANE_SEGMENTS") ? atoi(getenv("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knobs
-    static const int lane_t_g2 = getenv("ZG_PROVE_G2_SEGMENTS") ? atoi(getenv("ZG_PROVE_G2_SEGMENTS")) : 256;
+    static const int lane_t = zg_knob("ZG_PROVE_LANE_SEGMENTS") ? atoi(zg_knob("ZG_PROVE_LANE_SEGMENTS")) : 128;  // tuning knobs
+    static const int lane_t_g2 = zg_knob("ZG_PROVE_G2_SEGMENTS") ? atoi(zg_knob("ZG_PROVE_G2_SEGMENTS")) : 256;
     for (int i = 0; i < 4; i++) {
       const int t = i == 0 ? lane_t_g2 : lane_t;  // lane 0 runs the G2 evaluation, whose additions cost 3x
       const bool small = dense_hint[i] < (1u << 16);
@@ -428,7 +439,7 @@ struct ProvingKeyDev : PkBase {
         default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3]), nullptr); break;
       }
     };
-    static const bool serial_queue = getenv("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
+    static const bool serial_queue = zg_knob("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
     std::thread workers[4];
     // the head of the longest chain is queued before the lanes' threads are started (their creation is ~0.1 ms of this
     // thread's time, during which the device would have nothing of the H chain to run)
@@ -465,7 +476,7 @@ struct ProvingKeyDev : PkBase {
           if (l) hipStreamSynchronize(l->stream);
       }
     } drain{this};
-    if (const char* inj = getenv("ZG_TEST_FAIL_LANE")) {  // test hook: pretend that lane's queueing failed
+    if (const char* inj = zg_knob("ZG_TEST_FAIL_LANE")) {  // test hook: pretend that lane's queueing failed
       const int which = atoi(inj);
       if (which >= 0 && which < 4) lane_status[which] = ZG_ERR_HIP;
       if (which == 4) h_status = ZG_ERR_HIP;
@@ -544,6 +555,22 @@ struct ProvingKeyDev : PkBase {
     return read_h(out_form, h_out);
   }
   size_t domain_size() const override { return m; }
+#ifdef ZG_DEBUG_KNOBS
+  std::string debug_progress() const override {
+    auto state = [](hipError_t e) { return e == hipSuccess ? "done" : (e == hipErrorNotReady ? "PENDING" : "error"); };
+    std::string out = std::string("w_ready=") + state(hipEventQuery(w_ready)) + " main=" + state(hipStreamQuery(ctx->stream));
+    auto marks = [&](const zg_ctx* c) {
+      std::string m;
+      for (size_t i = 0; i < c->ev_used && i < c->ev_names.size(); i++)
+        m += std::string(" ") + c->ev_names[i] + ":" + state(hipEventQuery(c->ev_pool[i]));
+      return m;
+    };
+    out += " [main marks:" + marks(ctx) + "]";
+    for (int i = 0; i < 4; i++)
+      out += " lane" + std::to_string(i) + "=" + state(hipStreamQuery(lane[i]->stream)) + " [" + marks(lane[i]) + "]";
+    return out;
+  }
+#endif
 
   int read_h(int out_form, void* out) {
     hipStream_t st = ctx->stream;

@@ -11,6 +11,7 @@
 #include "curve_constants.h"
 #include "curve_quad29.cuh"
 #include "field29.cuh"
+#include "knobs.h"
 
 using namespace zg;
 
@@ -394,7 +395,7 @@ int check_quad_device(const GX& set_generator, int* bad_out) {
     const bool ok_dbl = same_point(got_dbl[i], xyzz_dbl(ha[i]));
     xyzz_add(r, ha[i]);
     const bool ok_mid = same_point(got_mid[i], r);
-    if (!(ok_add && ok_dbl && ok_mid) && getenv("ZG_SELFTEST_VERBOSE")) fprintf(stderr, "quad device case %d: add %d dbl %d mid %d\n", i, ok_add, ok_dbl, ok_mid);
+    if (!(ok_add && ok_dbl && ok_mid) && zg_knob("ZG_SELFTEST_VERBOSE")) fprintf(stderr, "quad device case %d: add %d dbl %d mid %d\n", i, ok_add, ok_dbl, ok_mid);
     bad += !ok_add + !ok_dbl + !ok_mid;
   }
   *bad_out += bad;

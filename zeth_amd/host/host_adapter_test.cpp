@@ -10,14 +10,27 @@
 //   prove CURVE pk assignment primary_inputs r_hex s_hex proof_fixed proof_random_1 proof_random_2
 //   multi_exp_sharded CURVE g1|g2 points scalars out_point n_shards     sharded_bases over n_shards contexts on device 0
 //   prove_pool CURVE pk assignment primary_inputs r_hex s_hex proof_a proof_b     device_proving_key_pool over {0, 0}
+//   prove_concurrent CURVE pk assignment primary_inputs r_hex s_hex n_threads proofs_per_thread out_prefix
+//          n_threads callers share ONE device_proving_key_pool (device 0, 4 proofs in flight); proof k of the run uses
+//          (r + k, s + 2k + 1) and is written to out_prefix.k; then the same threads call the stateless
+//          generate_proof(pk, primary, auxiliary) concurrently (out_prefix.sK, fresh randomness).  Prints the peak number
+//          of proofs that were in flight.
+//   bench_pool CURVE r1cs assignment primary_inputs n_threads proofs_per_thread in_flight proof_out
+//          key from fixed secrets (generator_from_secrets), then proofs/s through device_proving_key_pool; one JSON line
+//   keypair CURVE keypair_in pk_out vk_out vk_json keypair_out     keypair_read_bytes, then every writer (no GPU)
+//   swap_ab CURVE r1cs_in r1cs_out       r1cs_constraint_system::swap_AB_if_beneficial (no GPU); prints swapped / kept
 //   setup CURVE r1cs t_hex alpha_hex beta_hex delta_hex pk_out vk_out proof_out assignment primary_inputs
-//          r1cs_gg_ppzksnark_generator_from_secrets (gpu_groth16_generator.hpp) written as pk_out / vk_out; then
-//          generate_setup with fresh secrets: vk_out.fresh and a proof made with that key in proof_out
+//          r1cs_gg_ppzksnark_generator_from_secrets (gpu_groth16_generator.hpp) written as pk_out / vk_out and as
+//          pk_out.keypair (keypair_write_bytes); then generate_setup with fresh secrets: vk_out.fresh and a proof made
+//          with that key in proof_out
 //   prove_pb CURVE pk assignment primary_inputs pk2 proof_1 proof_2 proof_3
 //          the FIRST library call is generate_proof(pk, pb) (groth16_snark.hpp:32-35); then the host key is overwritten in
 //          place with pk2 (same address, same sizes) and proved again: the stale device copy must not be used; then the
 //          device keys are released and the key proved once more; the process must exit cleanly
+#include <atomic>
+#include <chrono>
 #include <iostream>
+#include <thread>
 
 #include "../../include/libzeth_gpu/gpu_groth16_generator.hpp"
 #include "../../include/libzeth_gpu/gpu_groth16_snark.hpp"
@@ -263,12 +276,216 @@ template<typename ppT> int cmd_prove_pool(char **argv)
         std::ifstream in_s = open_binary_input_file(argv[4]);
         r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[5]), in_s);
     }
-    device_proving_key_pool<ppT> pool(pk, {0, 0}); // two resident copies; on a node: one per device
+    device_proving_key_pool<ppT> pool(pk, {0, 0}, 1); // two resident copies, one prover each; on a node: one per device
     for (int k = 0; k < 2; k++) {
         const typename snarkT::proof proof = pool.prove(primary, auxiliary, from_hex<4>(argv[6]), from_hex<4>(argv[7]));
         std::ofstream out_s = open_binary_output_file(argv[8 + k]);
         snarkT::proof_write_bytes(proof, out_s);
     }
+    return 0;
+}
+
+template<typename ppT> Fr<ppT> add_small(Fr<ppT> x, uint64_t k)
+{
+    for (size_t i = 0; i < 4 && k; i++) {
+        const uint64_t before = x.data[i];
+        x.data[i] += k;
+        k = x.data[i] < before ? 1 : 0;
+    }
+    return x; // callers keep x + k below r
+}
+
+template<typename ppT> int cmd_prove_concurrent(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    typename snarkT::proving_key pk;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        snarkT::proving_key_read_bytes(pk, in_s);
+    }
+    r1cs_primary_input<Fr<ppT>> primary;
+    r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[4]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[5]), in_s);
+    }
+    const Fr<ppT> r0 = from_hex<4>(argv[6]), s0 = from_hex<4>(argv[7]);
+    const size_t n_threads = std::stoul(argv[8]), per_thread = std::stoul(argv[9]);
+    const std::string prefix = argv[10];
+    device_proving_key_pool<ppT> pool(pk, {0}, 4);
+    std::vector<typename snarkT::proof> proofs(n_threads * per_thread), stateless(n_threads);
+    std::vector<std::string> errors(n_threads);
+    std::atomic<size_t> ready(0);
+    auto worker = [&](size_t t) {
+        try {
+            ready++;
+            while (ready.load() < n_threads) { // all callers start together
+                std::this_thread::yield();
+            }
+            for (size_t j = 0; j < per_thread; j++) {
+                const size_t k = t * per_thread + j;
+                proofs[k] = pool.prove(primary, auxiliary, add_small<ppT>(r0, k), add_small<ppT>(s0, 2 * k + 1));
+            }
+            stateless[t] = snarkT::generate_proof(pk, primary, auxiliary);
+        } catch (const std::exception &e) {
+            errors[t] = e.what();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < n_threads; t++) {
+        threads.emplace_back(worker, t);
+    }
+    for (auto &th : threads) {
+        th.join();
+    }
+    for (size_t t = 0; t < n_threads; t++) {
+        if (!errors[t].empty()) {
+            std::cerr << "thread " << t << ": " << errors[t] << "\n";
+            return 1;
+        }
+    }
+    for (size_t k = 0; k < proofs.size(); k++) {
+        std::ofstream out_s = open_binary_output_file(prefix + "." + std::to_string(k));
+        snarkT::proof_write_bytes(proofs[k], out_s);
+    }
+    for (size_t t = 0; t < n_threads; t++) {
+        std::ofstream out_s = open_binary_output_file(prefix + ".s" + std::to_string(t));
+        snarkT::proof_write_bytes(stateless[t], out_s);
+    }
+    std::cout << "peak_in_flight " << pool.peak_in_flight() << " proofs " << pool.proofs_completed() << "\n";
+    return 0;
+}
+
+template<typename ppT> int cmd_bench_pool(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    using clock = std::chrono::steady_clock;
+    r1cs_constraint_system<Fr<ppT>> cs;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        r1cs_read_bytes(cs, in_s);
+    }
+    r1cs_primary_input<Fr<ppT>> primary;
+    r1cs_auxiliary_input<Fr<ppT>> auxiliary;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[4]);
+        r1cs_variable_assignment_read_bytes(primary, auxiliary, std::stoul(argv[5]), in_s);
+    }
+    const size_t n_threads = std::stoul(argv[6]), per_thread = std::stoul(argv[7]), in_flight = std::stoul(argv[8]);
+    auto t0 = clock::now();
+    // the secrets of tools/bench_prove.py, so that the proof can be compared with the oracle's on the same key
+    const r1cs_gg_ppzksnark_keypair<ppT> kp = r1cs_gg_ppzksnark_generator_from_secrets<ppT>(
+        cs, from_hex<4>("5a4554485f746175"), from_hex<4>("616c706861"), from_hex<4>("62657461"), from_hex<4>("64656c7461"));
+    const double keygen_s = std::chrono::duration<double>(clock::now() - t0).count();
+    t0 = clock::now();
+    device_proving_key_pool<ppT> pool(kp.pk, {0}, in_flight);
+    const Fr<ppT> r = from_hex<4>("1234567890abcdef1234567890abcdef"), s = from_hex<4>("fedcba0987654321fedcba0987654321");
+    const typename snarkT::proof first = pool.prove(primary, auxiliary, r, s);
+    const double upload_s = std::chrono::duration<double>(clock::now() - t0).count();
+    {
+        std::ofstream out_s = open_binary_output_file(argv[9]);
+        snarkT::proof_write_bytes(first, out_s);
+    }
+    // serial latency through the pool (one caller)
+    std::vector<double> lat;
+    for (int i = 0; i < 20; i++) {
+        const auto a = clock::now();
+        if (!(pool.prove(primary, auxiliary, r, s) == first)) {
+            std::cerr << "serial proof differs\n";
+            return 1;
+        }
+        lat.push_back(std::chrono::duration<double, std::milli>(clock::now() - a).count());
+    }
+    std::sort(lat.begin(), lat.end());
+    std::atomic<size_t> ready(0), bad(0);
+    std::atomic<bool> go(false);
+    auto worker = [&]() {
+        (void)pool.prove(primary, auxiliary, r, s); // creates this caller's prover before the clock starts
+        ready++;
+        while (!go.load()) {
+            std::this_thread::yield();
+        }
+        for (size_t j = 0; j < per_thread; j++) {
+            if (!(pool.prove(primary, auxiliary, r, s) == first)) {
+                bad++;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < n_threads; t++) {
+        threads.emplace_back(worker);
+    }
+    while (ready.load() < n_threads) {
+        std::this_thread::yield();
+    }
+    const auto a = clock::now();
+    go = true;
+    for (auto &th : threads) {
+        th.join();
+    }
+    const double wall = std::chrono::duration<double>(clock::now() - a).count();
+    if (bad.load()) {
+        std::cerr << bad.load() << " proofs differ from the serial proof\n";
+        return 1;
+    }
+    std::cout << "{\"metric\": \"groth16_prove_through_device_proving_key_pool\", \"curve\": \"" << ppT::name << "\", \"constraints\": "
+              << cs.num_constraints() << ", \"variables\": " << cs.num_variables() << ", \"callers\": " << n_threads
+              << ", \"in_flight_per_device\": " << in_flight << ", \"peak_in_flight\": " << pool.peak_in_flight() << ", \"proofs\": "
+              << n_threads * per_thread << ", \"wall_ms\": " << wall * 1e3 << ", \"proofs_per_s_per_gpu\": " << n_threads * per_thread / wall
+              << ", \"ms_per_proof_median_one_caller\": " << lat[lat.size() / 2] << ", \"ms_per_proof_min_one_caller\": " << lat[0]
+              << ", \"keygen_s\": " << keygen_s << ", \"upload_and_first_proof_s\": " << upload_s << ", \"all_equal_to_serial_proof\": true}\n";
+    return 0;
+}
+
+template<typename ppT> int cmd_keypair(char **argv)
+{
+    using snarkT = groth16_snark<ppT>;
+    typename snarkT::keypair kp;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        snarkT::keypair_read_bytes(kp, in_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[4]);
+        snarkT::proving_key_write_bytes(kp.pk, out_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[5]);
+        snarkT::verification_key_write_bytes(kp.vk, out_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[6]);
+        snarkT::verification_key_write_json(kp.vk, out_s);
+    }
+    {
+        // the verification key alone, read back through its own reader
+        std::stringstream ss;
+        snarkT::verification_key_write_bytes(kp.vk, ss);
+        typename snarkT::verification_key vk2;
+        snarkT::verification_key_read_bytes(vk2, ss);
+        kp.vk = vk2;
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(argv[7]);
+        snarkT::keypair_write_bytes(kp, out_s);
+    }
+    std::cout << "keypair ok: " << kp.pk.A_query.size() << " A, " << kp.vk.ABC_g1.size() << " ABC\n";
+    return 0;
+}
+
+template<typename ppT> int cmd_swap_ab(char **argv)
+{
+    r1cs_constraint_system<Fr<ppT>> cs;
+    {
+        std::ifstream in_s = open_binary_input_file(argv[3]);
+        r1cs_read_bytes(cs, in_s);
+    }
+    const bool swapped = cs.swap_AB_if_beneficial();
+    {
+        std::ofstream out_s = open_binary_output_file(argv[4]);
+        r1cs_write_bytes(cs, out_s);
+    }
+    std::cout << (swapped ? "swapped" : "kept") << "\n";
     return 0;
 }
 
@@ -335,7 +552,11 @@ template<typename ppT> int cmd_setup(char **argv)
     }
     {
         std::ofstream out_s = open_binary_output_file(argv[9]);
-        verification_key_write_bytes<ppT>(kp.vk, out_s);
+        snarkT::verification_key_write_bytes(kp.vk, out_s);
+    }
+    {
+        std::ofstream out_s = open_binary_output_file(std::string(argv[8]) + ".keypair");
+        snarkT::keypair_write_bytes(kp, out_s);
     }
     // generate_setup: fresh secrets; the key must prove (checked by the caller with the verification key written here)
     const r1cs_gg_ppzksnark_keypair<ppT> fresh = generate_setup<ppT>(cs);
@@ -351,7 +572,7 @@ template<typename ppT> int cmd_setup(char **argv)
     }
     {
         std::ofstream out_s = open_binary_output_file(std::string(argv[9]) + ".fresh");
-        verification_key_write_bytes<ppT>(fresh.vk, out_s);
+        snarkT::verification_key_write_bytes(fresh.vk, out_s);
     }
     return 0;
 }
@@ -475,6 +696,18 @@ template<typename ppT> int run(int argc, char **argv)
     }
     if (cmd == "prove_pb" && argc >= 10) {
         return cmd_prove_pb<ppT>(argv);
+    }
+    if (cmd == "prove_concurrent" && argc >= 11) {
+        return cmd_prove_concurrent<ppT>(argv);
+    }
+    if (cmd == "bench_pool" && argc >= 10) {
+        return cmd_bench_pool<ppT>(argv);
+    }
+    if (cmd == "keypair" && argc >= 8) {
+        return cmd_keypair<ppT>(argv);
+    }
+    if (cmd == "swap_ab" && argc >= 5) {
+        return cmd_swap_ab<ppT>(argv);
     }
     std::cerr << "usage: see the head of host_adapter_test.cpp\n";
     return 2;
