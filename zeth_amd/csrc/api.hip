@@ -76,7 +76,11 @@ int zg_sizes(int curve, size_t* fr, size_t* fq, size_t* g1, size_t* g2) {
   return ZG_OK;
 }
 
-int zg_ctx_create(int device, zg_ctx** out) { return zg_ctx_create_prio(device, +1, out); }
+int zg_ctx_create(int device, zg_ctx** out) {
+  // (debug builds: ZG_CTX_PRIO = 1 | 0 | -1, for tools/diag_prio.py)
+  static const int prio = zg_knob("ZG_CTX_PRIO") ? atoi(zg_knob("ZG_CTX_PRIO")) : +1;
+  return zg_ctx_create_prio(device, prio, out);
+}
 
 
 }  // extern "C"
@@ -520,9 +524,15 @@ int zg_witness_map(zg_pk* pk, const void* primary, size_t n_primary, const void*
 }
 
 #ifdef ZG_DEBUG_KNOBS
+}  // extern "C"
+const char* volatile zg_crumbs[8] = {"-", "-", "-", "-", "-", "-", "-", "-"};
+thread_local int zg_crumb_slot = 4;
+extern "C" {
 int zg_debug_pk_progress(zg_pk* pk, char* buf, size_t cap) {
   if (!pk || !buf || !cap) return ZG_ERR_INVALID_ARGUMENT;
-  const std::string s = pk->impl->debug_progress();
+  std::string s = pk->impl->debug_progress();
+  s += " crumbs:";
+  for (int i = 0; i < 5; i++) s += std::string(" [") + std::to_string(i) + "] " + zg_crumbs[i];
   snprintf(buf, cap, "%s", s.c_str());
   return ZG_OK;
 }

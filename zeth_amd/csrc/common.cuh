@@ -62,6 +62,7 @@ struct zg_ctx {
   uint32_t job_dense = 0;  // scalars other than 0/1 seen by the last MSM on this context
   int pinned_reserve(size_t bytes) {
     if (bytes <= pinned_cap) return ZG_OK;
+    ZG_CRUMB("pinned_reserve: hipHostFree/hipHostMalloc");
     if (pinned) ZG_HIP(hipHostFree(pinned));
     pinned = nullptr;
     pinned_cap = 0;
@@ -81,12 +82,16 @@ struct zg_ctx {
   int ws_reserve(size_t bytes) {
     ws_used = 0;
     if (bytes <= ws_cap) return ZG_OK;
+    ZG_CRUMB("ws_reserve: hipStreamSynchronize");
     ZG_HIP(hipStreamSynchronize(stream));
+    ZG_CRUMB("ws_reserve: hipFree");
     if (ws) ZG_HIP(hipFree(ws));
     ws = nullptr;
     ws_cap = 0;
     size_t want = bytes + (bytes >> 3) + (1u << 20);
+    ZG_CRUMB("ws_reserve: hipMalloc");
     ZG_HIP(hipMalloc((void**)&ws, want));
+    ZG_CRUMB("ws_reserve: done");
     ws_cap = want;
     return ZG_OK;
   }

@@ -13,3 +13,16 @@ inline const char* zg_knob(const char* name) {
   return nullptr;
 #endif
 }
+
+// Breadcrumbs (debug builds only): the last library step each queueing thread of a proof entered, readable by a watchdog
+// while that thread is blocked inside a runtime call (zg_debug_pk_progress, tools/diag_prio.py).  Slot 0-3: the lanes'
+// threads, 4: the calling thread.
+#ifdef ZG_DEBUG_KNOBS
+extern const char* volatile zg_crumbs[8];
+extern thread_local int zg_crumb_slot;
+#define ZG_CRUMB(text) (zg_crumbs[zg_crumb_slot & 7] = (text))
+#define ZG_CRUMB_SLOT(i) (zg_crumb_slot = (i))
+#else
+#define ZG_CRUMB(text) ((void)0)
+#define ZG_CRUMB_SLOT(i) ((void)0)
+#endif

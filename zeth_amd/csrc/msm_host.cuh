@@ -189,7 +189,9 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->job_c = p.c;
   ctx->job_table_gbits = tab ? p.gbits : -1;
   const int rows = tab ? 2 * p.W : p.W;  // window sums; table mode: weighted group sums, then plain group sums
+  ZG_CRUMB("msm_launch: pinned_reserve");
   ZG_TRY(ctx->pinned_reserve((size_t)rows * sizeof(XYZZ<F>) + 256));
+  ZG_CRUMB("msm_launch: after pinned_reserve");
   const size_t WN = tab ? p.E : (size_t)p.W * n;  // entries
   if ((uint64_t)WN >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 32-bit entry positions with headroom
   const size_t WB = (size_t)p.W * p.nb, WC = (size_t)p.W * p.cap;
@@ -240,6 +242,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   const size_t lds = (size_t)p.nb * 4;
   static std::once_flag attr_once;  // several lanes of a proof may arrive here at once
   hipError_t attr_err = hipSuccess;
+  ZG_CRUMB("msm_launch: call_once hipFuncSetAttribute");
   std::call_once(attr_once, [&] {
     attr_err = hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
     if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
@@ -249,6 +252,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ZG_HIP(attr_err);
   ctx->prof_begin();
   ctx->mark("digits");
+  ZG_CRUMB("msm_launch: first kernel launch (k_zero_u32)");
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
                      (size_t)(p.W + 1 + 64), heavy, gcnt, (size_t)(tab ? 129 : 0));
   uint32_t* dense_counters = ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr;
@@ -285,6 +289,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     hipLaunchKernelGGL(k_hist, dim3(p.nchunk, p.W), dim3(1024), lds, st, dig, n, p.nb, p.nchunk, cnt);
   }
   ctx->mark("scan");
+  ZG_CRUMB("msm_launch: k_scan launch");
   hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits, nhi,
                      cursor1, pstart, lencur, ffirst, gstart);
   ctx->mark("scatter");
@@ -341,6 +346,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   hipLaunchKernelGGL(k_units_heavy, dim3(8, 128), dim3(256), 0, st, cnt, boff, ufirst, ffirst, p.nb, p.L, p.cap, units, lencur,
                      order, heavy, p.smax);
   ctx->mark("accum");
+  ZG_CRUMB("msm_launch: k_accum launch");
   const dim3 ablk(ZG_ACCUM_BLOCK);
   const uint32_t ablocks = (p.cap + ZG_ACCUM_BLOCK - 1) / ZG_ACCUM_BLOCK;
   hipLaunchKernelGGL((k_accum<F>), tab ? dim3(g0, ablocks) : dim3(ablocks, g0), ablk, 0, st, units, wunits, p.cap, order, sorted,
@@ -367,6 +373,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                          COMBINE_CHUNK * COMBINE_CHUNK, part, wunits + p.W);
   }
   ctx->mark("reduce1");
+  ZG_CRUMB("msm_launch: k_reduce1 launch");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((4 * p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
                      p.k, p.L, (uint32_t)p.W, seg, tab ? seg + (size_t)p.W * p.T : (XYZZ<F>*)nullptr);
   ctx->mark("reduce2");
@@ -388,10 +395,13 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   }
   ctx->mark("end");
   ZG_HIP(hipGetLastError());
+  ZG_CRUMB("msm_launch: hipMemcpy2DAsync D2H");
   // gather the W window sums (strided by T) with one 2D copy into pinned host memory
   ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), rows,
                           hipMemcpyDeviceToHost, st));
+  ZG_CRUMB("msm_launch: hipMemcpyAsync D2H (dense counters)");
   ZG_HIP(hipMemcpyAsync((char*)ctx->pinned + (size_t)rows * sizeof(XYZZ<F>), wunits + p.W + 1, 256, hipMemcpyDeviceToHost, st));
+  ZG_CRUMB("msm_launch: queued");
   return ZG_OK;
 }
 
@@ -402,7 +412,9 @@ int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
   Affine<F> res = Affine<F>::inf();
   XYZZ<F> acc = XYZZ<F>::inf();
   if (ctx->job_n > 0) {
+    ZG_CRUMB("msm_finish: hipStreamSynchronize");
     ZG_HIP(hipStreamSynchronize(ctx->stream));
+    ZG_CRUMB("msm_finish: synchronised");
     ctx->prof_end();
     const XYZZ<F>* rows = reinterpret_cast<const XYZZ<F>*>(ctx->pinned);
     int nrows = ctx->job_W;

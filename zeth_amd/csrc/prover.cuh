@@ -372,6 +372,8 @@ struct ProvingKeyDev : PkBase {
     auto stamp = [&](const char* what) {
       if (trace) fprintf(stderr, "  [prove] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
     };
+    ZG_CRUMB_SLOT(4);
+    ZG_CRUMB("prove: load_assignment");
     ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
     stamp("assignment queued");
     hipStream_t st = ctx->stream;
@@ -427,9 +429,17 @@ struct ProvingKeyDev : PkBase {
       lane[i]->reduce_segments = (small && t > 0 && (t & (t - 1)) == 0) ? (uint32_t)t : 0u;
     }
     int lane_status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
+    // (debug builds: ZG_LANE_MASK, bit i clear = lane i's evaluation is skipped -- wrong proofs, for tools/diag_prio.py)
+    static const int lane_mask = zg_knob("ZG_LANE_MASK") ? atoi(zg_knob("ZG_LANE_MASK")) : 15;
     auto queue_lane = [&](int i) {
       if (hipSetDevice(ctx->device) != hipSuccess) {
         lane_status[i] = ZG_ERR_HIP;
+        return;
+      }
+      ZG_CRUMB_SLOT(i);
+      ZG_CRUMB("lane thread started");
+      if (!((lane_mask >> i) & 1)) {
+        lane[i]->job_n = 0;
         return;
       }
       switch (i) {
@@ -444,7 +454,9 @@ struct ProvingKeyDev : PkBase {
     // the head of the longest chain is queued before the lanes' threads are started (their creation is ~0.1 ms of this
     // thread's time, during which the device would have nothing of the H chain to run)
     const bool head_first = h_status == ZG_OK && hold == 0;
+    ZG_CRUMB("prove: qap_h head");
     if (head_first) h_status = qap_h(0, 0);
+    ZG_CRUMB("prove: starting lane threads");
     if (!serial_queue) {
       for (int i = 0; i < 4; i++) {
         try {
@@ -454,9 +466,12 @@ struct ProvingKeyDev : PkBase {
         }
       }
     }
+    ZG_CRUMB("prove: qap_h rest");
     if (h_status == ZG_OK && !(hold >= 3)) h_status = qap_h(hold >= 1 && hold <= 3 ? hold : (head_first ? 1 : 0), 2);
+    ZG_CRUMB("prove: H msm_launch");
     const MsmTable h_tab{H_len, 0, H_c, H_levels};
     if (h_status == ZG_OK) h_status = o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr);
+    ZG_CRUMB("prove: joining lane threads");
     for (int i = 0; i < 4; i++) {
       if (workers[i].joinable())
         workers[i].join();
