@@ -129,7 +129,7 @@ int zg_selftest_reduced_radix(int field, int iters, uint64_t seed, int* mismatch
 /* The quad-lane point arithmetic of the combine and reduction kernels (curve_quad.cuh, curve_quad29.cuh) against the
  * one-lane formulas: curve_group 0 alt_bn128 G1, 1 BLS12-377 G1, 2 alt_bn128 G2, 3 BLS12-377 G2.  The first runs the
  * kernels' templates on the host (four threads stand in for the four lanes; no GPU needed); the second runs them on the
- * current device (groups 0 and 1: 32-bit limbs and the reduced radix).  No counterpart in the reference. */
+ * current device (G1: 32-bit limbs and the reduced radix; G2: the Fq2 instantiations).  No counterpart in the reference. */
 int zg_selftest_quad_lanes(int curve_group, int* mismatches);
 int zg_selftest_quad_lanes_device(int curve_group, int* mismatches);
 

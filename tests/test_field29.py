@@ -49,10 +49,11 @@ def test_quad_lane_point_arithmetic_matches_one_lane_formulas(group):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("group", [0, 1])
+@pytest.mark.parametrize("group", [0, 1, 2, 3])
 def test_quad_lane_point_arithmetic_on_the_device(group):
-    """The same templates as compiled for gfx950 (32-bit limbs and the reduced radix): 68 additions and doublings with
-    every exceptional case, compared on the host with the one-lane formulas."""
+    """The same templates as compiled for gfx950 (G1: 32-bit limbs and the reduced radix; G2: the Fq2 instantiations on
+    32-bit limbs): 68 additions and doublings with every exceptional case, compared on the host with the one-lane
+    formulas -- every instantiation that ships is checked on the device it ships for."""
     L = zl.load_library()
     L.zg_selftest_quad_lanes_device.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.zg_selftest_quad_lanes_device.restype = ctypes.c_int

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -26,6 +27,24 @@
     int _s = (expr);          \
     if (_s != ZG_OK) return _s; \
   } while (0)
+
+// hipStreamSynchronize with a polling phase first.  The runtime's blocking wait wakes its caller 50-150 us after the
+// stream has drained (measured: the wall time of a 0.5-1 ms multi-exponentiation moved in steps of ~0.15 ms while its
+// kernels' times did not, profiles/r3_tune_table_c.jsonl); a result that the host tail is waiting for is therefore polled
+// (hipStreamQuery, ~1 us a call) for up to `spin_us` before the thread gives up its core to the blocking wait.
+inline hipError_t zg_stream_wait(hipStream_t st, unsigned spin_us = 4000) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > (long)spin_us) break;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  (void)hipGetLastError();  // hipErrorNotReady is not an error to keep
+  return hipStreamSynchronize(st);
+}
 
 struct NttDomainBase {
   virtual ~NttDomainBase() {}
@@ -54,6 +73,7 @@ struct zg_ctx {
   size_t job_n = 0;
   int job_W = 0, job_c = 0;
   int job_table_gbits = -1;  // >= 0: the job ran in fixed-base table mode with 2^gbits bucket groups
+  int job_rows = 0, job_log_t = 0, job_log_k = 0;  // rows the host reads; log2 of segments per group and buckets per segment
   bool want_dense = false;  // count scalars other than 0/1 during recoding (prover lanes)
   // Bucket segments per window of the reduction (power of two; 0: the plan's own choice).  A caller whose evaluation is
   // not on its critical path (the prover's side lanes) asks for fewer: each segment's lane then pays the c-bit weighting

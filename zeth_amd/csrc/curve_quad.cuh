@@ -107,12 +107,17 @@ ZG_HD int quad_bcast_flag(bool f, int lane) {
 #if !defined(__HIP_DEVICE_COMPILE__)
   return quad_host()->exchange(v, quad_host_lane(), lane);
 #else
+  int r;
   switch (lane) {
-    case 0: return __builtin_amdgcn_mov_dpp(v, quad_bcast(0), 0xF, 0xF, true);
-    case 1: return __builtin_amdgcn_mov_dpp(v, quad_bcast(1), 0xF, 0xF, true);
-    case 2: return __builtin_amdgcn_mov_dpp(v, quad_bcast(2), 0xF, 0xF, true);
-    default: return __builtin_amdgcn_mov_dpp(v, quad_bcast(3), 0xF, 0xF, true);
+    case 0: r = __builtin_amdgcn_mov_dpp(v, quad_bcast(0), 0xF, 0xF, true); break;
+    case 1: r = __builtin_amdgcn_mov_dpp(v, quad_bcast(1), 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_mov_dpp(v, quad_bcast(2), 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_mov_dpp(v, quad_bcast(3), 0xF, 0xF, true); break;
   }
+#if ZG_QUAD_DPP_STANDALONE
+  asm volatile("" : "+v"(r));  // kept an instruction of its own, like the moves of quad_perm
+#endif
+  return r;
 #endif
 }
 // true when the flag is set on any lane of the wave (host: of the quad): the condition of a branch that every quad must

@@ -95,7 +95,9 @@ static constexpr int MSM_TABLE_MIN_C = 10, MSM_TABLE_MAX_C = 22;
 // the 13th digit has 2 bits, four buckets take a quarter of all scalars each, and the accumulation runs 60 % longer.
 inline int msm_table_pick_c(size_t N) {
   int lg = ilog2_floor(N ? N : 1) + ((N & (N - 1)) ? 1 : 0);
-  return lg >= 23 ? 22 : 20;
+  // (up to 2^16 bases 17 bits: two more additions per scalar, but an eighth of the buckets to reduce -- 0.50 against
+  // 0.57 ms of kernels at 2^16 bases, a tie at 2^17, 20 bits ahead from 2^18: profiles/r3_tune_table_c.jsonl)
+  return lg >= 23 ? 22 : (lg <= 16 ? 17 : 20);
 }
 
 // window width for n scalars that are not 0 or 1, tuned on MI355X (tools/tune_c.py): odd widths keep the
@@ -205,7 +207,11 @@ inline MsmPlan msm_make_table_plan(size_t n, int scalar_bits, int c, int D) {
   if (maxchunk < 1) maxchunk = 1;
   if (nchunk > maxchunk) nchunk = maxchunk;
   p.nchunk = nchunk;
+  // Segments cost no weighting in table mode (k_bitsum), so a group is cut into as many as keep the device at one to two
+  // waves of quads per SIMD (32768 quads in all; more only lengthens the tree over the segment sums), down to two
+  // buckets a segment: 2^16 buckets (c = 17) run as 16384 segments of 4 -- a chain of 8 additions -- instead of 4096 of 16
   p.T = p.nb < 1024 ? p.nb : (p.nb >= 32768 ? 2048 : 1024);
+  while (p.T * 4 <= p.nb && (size_t)p.T * 2 * (size_t)p.W <= 32768) p.T <<= 1;
   msm_cap_segments(p);
   if (const char* e = zg_knob("ZG_MSM_SEGMENTS")) {
     uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
@@ -1049,26 +1055,32 @@ template <class F>
 __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
                                                   const XYZZ<F>* __restrict__ part, uint32_t nb, uint32_t T, uint32_t k,
                                                   uint32_t L, uint32_t W, XYZZ<F>* __restrict__ seg,
-                                                  XYZZ<F>* __restrict__ seg_plain /* table mode: unweighted segment sums; else null */) {
+                                                  XYZZ<F>* __restrict__ seg_plain /* table mode: unweighted segment sums; else null */,
+                                                  uint32_t weighted /* 0 (table mode): seg gets sum (i + 1) B_{jk+i} only */) {
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
   if (g >= T * W) return;
   const uint32_t w = g / T, j = g % T;
   using Q = QuadOps<F>;
   using Coord = typename Q::Coord;
   Coord run = Q::zero(), tot = Q::zero();  // the identity: every coordinate zero
+  // (the three dependent loads at the head of each step -- count, first unit, bucket sum -- are not what bounds this
+  // kernel: with the loads running two buckets ahead of the additions it took the same time, 0.28-0.36 ms for 2^19
+  // buckets; at two waves per SIMD it is bound by the issue of the additions themselves, ~6,500 cycles each)
   for (int bb = (int)k - 1; bb >= 0; bb--) {
     const size_t gid = (size_t)w * nb + (size_t)j * k + (uint32_t)bb;
     if (cnt[gid]) run = Q::add(run, Q::load(part + ufirst[gid], q), q);  // k_combine left the bucket sum in its first unit
     tot = Q::add(tot, run, q);
   }
-  // tot = sum (b - j*k + 1) B_b ; add (j*k) * run, j*k < nb
-  const uint32_t start = j * k;
-  Coord r = Q::zero();
-  for (int b = 31 - __builtin_clz(nb > 1 ? nb - 1 : 1); b >= 0; b--) {
-    r = Q::dbl(r, q);
-    if ((start >> b) & 1u) r = Q::add(r, run, q);
+  if (weighted) {
+    // tot = sum (b - j*k + 1) B_b ; add (j*k) * run, j*k < nb
+    const uint32_t start = j * k;
+    Coord r = Q::zero();
+    for (int b = 31 - __builtin_clz(nb > 1 ? nb - 1 : 1); b >= 0; b--) {
+      r = Q::dbl(r, q);
+      if ((start >> b) & 1u) r = Q::add(r, run, q);
+    }
+    tot = Q::add(tot, r, q);
   }
-  tot = Q::add(tot, r, q);
   Q::store(seg + g, q, tot);
   if (seg_plain) Q::store(seg_plain + g, q, run);
 }
@@ -1104,6 +1116,45 @@ __global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict
         Q::store(s + (size_t)qi * stride, q, r);
     }
     __syncthreads();
+  }
+}
+
+// Table mode: the weights of the segment sums without a multiplication per segment.  k_reduce1 leaves, for the flat
+// segment index I = group * T + j, the plain sum X[I] and the locally weighted sum Y[I] of its k buckets.  What the host
+// needs is  sum_I Y[I],  S = sum_I X[I]  and  sum_I I' X[I]  for I' = j (bucket weights) and I' = group (group weights):
+// every such weighted sum is  sum_t 2^t BIT_t  with  BIT_t = sum over the I whose bit t is set of X[I].  All BIT_t come out
+// of ONE pairwise tree over X, in place: at level u a node (2^(u+1) entries from i) adds its right half's head into its
+// left half's head -- X[i] += X[i + 2^u] -- and does the same for the bit sums below u, which live at X[i + 2^t]:
+// X[i + 2^t] += X[i + 2^u + 2^t], t < u; the right head X[i + 2^u] itself IS the node's bit-u sum and stays where it is.
+// After log2 N levels X[0] = S and X[2^t] = BIT_t.  2 N additions in all instead of the ~1.5 log2(buckets) doublings and
+// additions every segment paid for its weight (40-65 % of the reduction's instructions), in a chain of log2 N additions;
+// the host then runs two Horner chains of log2 N steps on single points, which it does ten times faster than a quad.
+//   grid.x blocks of 2^hi entries each run the levels [lo, hi); Y (the other sums) is tree-summed alongside.
+//   rows (last launch only): Y total, S, BIT_0 .. BIT_(hi-1) in the form the host reads.
+template <class F>
+__global__ void __launch_bounds__(quad_block<F>()) k_bitsum(XYZZ<F>* __restrict__ X, XYZZ<F>* __restrict__ Y, uint32_t lo, uint32_t hi,
+                                                           XYZZ<F>* __restrict__ rows /* null except in the last launch */) {
+  using Q = QuadOps<F>;
+  const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
+  XYZZ<F>* x = X + ((size_t)blockIdx.x << hi);
+  XYZZ<F>* y = Y + ((size_t)blockIdx.x << hi);
+  for (uint32_t u = lo; u < hi; u++) {
+    const uint32_t nodes = 1u << (hi - u - 1), per = u + 2;  // per node: S, the u bit sums below, and Y
+    for (uint32_t item = qi; item < nodes * per; item += nq) {
+      const uint32_t node = item / per, e = item % per;
+      const size_t i = (size_t)node << (u + 1);
+      XYZZ<F>* base = e == u + 1 ? y : x;
+      const size_t o = (e == 0 || e == u + 1) ? 0 : ((size_t)1 << (e - 1));
+      const typename Q::Coord r = Q::add(Q::load(base + i + o, q), Q::load(base + i + ((size_t)1 << u) + o, q), q);
+      Q::store(base + i + o, q, r);
+    }
+    __syncthreads();
+  }
+  if (rows && blockIdx.x == 0) {
+    for (uint32_t item = qi; item < hi + 2; item += nq) {
+      const XYZZ<F>* src = item == 0 ? y : (item == 1 ? x : x + ((size_t)1 << (item - 2)));
+      Q::store_final(rows + item, q, Q::load(src, q));
+    }
   }
 }
 

@@ -188,9 +188,17 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->job_W = p.W;
   ctx->job_c = p.c;
   ctx->job_table_gbits = tab ? p.gbits : -1;
-  const int rows = tab ? 2 * p.W : p.W;  // window sums; table mode: weighted group sums, then plain group sums
+  const int rows = tab ? 2 * p.W : p.W;  // rows of segment sums; table mode: locally weighted sums, then plain sums
+  // what the host reads: the W window sums, or (table mode) the sum of the weighted rows, the plain total and one sum per
+  // bit of the flat segment index (k_bitsum)
+  unsigned log_nt = 0;
+  while (((size_t)1 << log_nt) < (size_t)p.W * p.T) log_nt++;
+  const int out_rows = tab ? (int)log_nt + 2 : p.W;
+  ctx->job_rows = out_rows;
+  ctx->job_log_t = (int)ilog2_floor(p.T);
+  ctx->job_log_k = (int)ilog2_floor(p.k);
   ZG_CRUMB("msm_launch: pinned_reserve");
-  ZG_TRY(ctx->pinned_reserve((size_t)rows * sizeof(XYZZ<F>) + 256));
+  ZG_TRY(ctx->pinned_reserve((size_t)out_rows * sizeof(XYZZ<F>) + 256));
   ZG_CRUMB("msm_launch: after pinned_reserve");
   const size_t WN = tab ? p.E : (size_t)p.W * n;  // entries
   if ((uint64_t)WN >= (1ull << 31)) return ZG_ERR_UNSUPPORTED;  // 32-bit entry positions with headroom
@@ -201,6 +209,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
                 zg_ctx::ws_round((p.W + 1 + 64) * 4) + zg_ctx::ws_round(WC * sizeof(UnitDesc)) + zg_ctx::ws_round(WC * 4) +
                 zg_ctx::ws_round((size_t)p.W * UNIT_CLASS_STRIDE * 4) +
                 zg_ctx::ws_round(WC * sizeof(XYZZ<F>)) + zg_ctx::ws_round((size_t)rows * p.T * sizeof(XYZZ<F>)) +
+                zg_ctx::ws_round((size_t)(log_nt + 2) * sizeof(XYZZ<F>)) +
                 (tab ? zg_ctx::ws_round(WN * 4) + 3 * zg_ctx::ws_round(129 * 4) : 0);
   ZG_TRY(ctx->ws_reserve(need));
   int16_t* dig = ctx->ws_take<int16_t>(WN);
@@ -217,6 +226,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   uint32_t* lencur = ctx->ws_take<uint32_t>((size_t)p.W * UNIT_CLASS_STRIDE);
   XYZZ<F>* part = ctx->ws_take<XYZZ<F>>(WC);
   XYZZ<F>* seg = ctx->ws_take<XYZZ<F>>((size_t)rows * p.T);
+  XYZZ<F>* bit_rows = ctx->ws_take<XYZZ<F>>(log_nt + 2);
   uint32_t *fent = nullptr, *gcnt = nullptr, *gstart = nullptr, *gcursor = nullptr;
   if (tab) {
     fent = ctx->ws_take<uint32_t>(WN);
@@ -235,7 +245,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     pstart = ctx->ws_take<uint32_t>((size_t)p.W * (nhi + 1));
     if (!mid_ent || !mid_lo || !cursor1 || !pstart) return ZG_ERR_OUT_OF_MEMORY;
   }
-  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !ffirst || !heavy || !wunits || !units || !order || !lencur || !part || !seg)
+  if (!dig || !sorted || !cnt || !cursor || !boff || !ufirst || !ffirst || !heavy || !wunits || !units || !order || !lencur || !part || !seg || !bit_rows)
     return ZG_ERR_OUT_OF_MEMORY;
 
   hipStream_t st = ctx->stream;
@@ -375,9 +385,26 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->mark("reduce1");
   ZG_CRUMB("msm_launch: k_reduce1 launch");
   hipLaunchKernelGGL((k_reduce1<F>), dim3((4 * p.T * p.W + 127) / 128), dim3(128), 0, st, cnt, ufirst, part, p.nb, p.T,
-                     p.k, p.L, (uint32_t)p.W, seg, tab ? seg + (size_t)p.W * p.T : (XYZZ<F>*)nullptr);
+                     p.k, p.L, (uint32_t)p.W, seg, tab ? seg + (size_t)p.W * p.T : (XYZZ<F>*)nullptr, tab ? 0u : 1u);
   ctx->mark("reduce2");
-  {
+  if (tab) {
+    // the weights come from the bit sums of the plain segment sums (k_bitsum): blocks of two entries per quad first,
+    // then one block over the block heads
+    const uint32_t nq = (uint32_t)quad_block<F>() / 4;
+    unsigned chunk_log = 0;
+    while ((1u << chunk_log) < 2 * nq) chunk_log++;
+    XYZZ<F>* X = seg + (size_t)p.W * p.T;
+    if (log_nt <= chunk_log) {
+      hipLaunchKernelGGL((k_bitsum<F>), dim3(1), dim3(4 * nq), 0, st, X, seg, 0u, log_nt, bit_rows);
+    } else {
+      hipLaunchKernelGGL((k_bitsum<F>), dim3(1u << (log_nt - chunk_log)), dim3(4 * nq), 0, st, X, seg, 0u, chunk_log, (XYZZ<F>*)nullptr);
+      hipLaunchKernelGGL((k_bitsum<F>), dim3(1), dim3(4 * nq), 0, st, X, seg, chunk_log, log_nt, bit_rows);
+    }
+    ctx->mark("end");
+    ZG_HIP(hipGetLastError());
+    ZG_CRUMB("msm_launch: hipMemcpyAsync D2H");
+    ZG_HIP(hipMemcpyAsync(ctx->pinned, bit_rows, (size_t)out_rows * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+  } else {
     const uint32_t nq = (uint32_t)quad_block<F>() / 4;  // quads of a full block
     if (p.T > nq && p.T % nq == 0) {
       // chunks of one entry per quad, then the chunk heads
@@ -392,15 +419,15 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
       if (t2 < 64) t2 = 64;
       hipLaunchKernelGGL((k_reduce2<F>), dim3(rows, 1), dim3(t2), 0, st, seg, p.T, p.T, 1u, 1);
     }
+    ctx->mark("end");
+    ZG_HIP(hipGetLastError());
+    ZG_CRUMB("msm_launch: hipMemcpy2DAsync D2H");
+    // gather the W window sums (strided by T) with one 2D copy into pinned host memory
+    ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), rows,
+                            hipMemcpyDeviceToHost, st));
   }
-  ctx->mark("end");
-  ZG_HIP(hipGetLastError());
-  ZG_CRUMB("msm_launch: hipMemcpy2DAsync D2H");
-  // gather the W window sums (strided by T) with one 2D copy into pinned host memory
-  ZG_HIP(hipMemcpy2DAsync(ctx->pinned, sizeof(XYZZ<F>), seg, (size_t)p.T * sizeof(XYZZ<F>), sizeof(XYZZ<F>), rows,
-                          hipMemcpyDeviceToHost, st));
   ZG_CRUMB("msm_launch: hipMemcpyAsync D2H (dense counters)");
-  ZG_HIP(hipMemcpyAsync((char*)ctx->pinned + (size_t)rows * sizeof(XYZZ<F>), wunits + p.W + 1, 256, hipMemcpyDeviceToHost, st));
+  ZG_HIP(hipMemcpyAsync((char*)ctx->pinned + (size_t)out_rows * sizeof(XYZZ<F>), wunits + p.W + 1, 256, hipMemcpyDeviceToHost, st));
   ZG_CRUMB("msm_launch: queued");
   return ZG_OK;
 }
@@ -413,27 +440,36 @@ int msm_finish(zg_ctx* ctx, int out_form, void* out_affine_host) {
   XYZZ<F> acc = XYZZ<F>::inf();
   if (ctx->job_n > 0) {
     ZG_CRUMB("msm_finish: hipStreamSynchronize");
-    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    ZG_HIP(zg_stream_wait(ctx->stream));
     ZG_CRUMB("msm_finish: synchronised");
     ctx->prof_end();
     const XYZZ<F>* rows = reinterpret_cast<const XYZZ<F>*>(ctx->pinned);
-    int nrows = ctx->job_W;
+    const int nrows = ctx->job_rows;
     if (ctx->job_table_gbits >= 0) {
-      // bucket (group g, key k) weighs k * W + g + 1; rows: R_g = sum_k (k + 1) B_gk, then S_g = sum_k B_gk:
-      //   sum = W * (sum_g R_g - sum_g S_g) + sum_g (g + 1) S_g
-      const int W = ctx->job_W;
-      nrows = 2 * W;
-      XYZZ<F> run = XYZZ<F>::inf(), tot = XYZZ<F>::inf(), a = XYZZ<F>::inf();
-      for (int g = W - 1; g >= 0; g--) {
-        xyzz_add(run, rows[W + g]);
-        xyzz_add(tot, run);
-        xyzz_add(a, rows[g]);
+      // rows: Y = sum of the segments' locally weighted sums, S = sum of all buckets, BIT_t = sum of the plain segment sums
+      // whose flat index (group * T + j) has bit t set.  Bucket (group g, key kappa = j k + i) weighs kappa * W + g + 1:
+      //   sum = W * (R - S) + S + sum_t 2^t BIT_(log T + t),   R = Y + k * sum_(t < log T) 2^t BIT_t
+      const XYZZ<F>& Y = rows[0];
+      const XYZZ<F>& S = rows[1];
+      const XYZZ<F>* BIT = rows + 2;
+      const int log_t = ctx->job_log_t, gbits = ctx->job_table_gbits;
+      XYZZ<F> r = XYZZ<F>::inf();
+      for (int t = log_t - 1; t >= 0; t--) {
+        r = xyzz_dbl(r);
+        xyzz_add(r, BIT[t]);
       }
-      run.y = F::neg(run.y);  // run = sum_g S_g
-      xyzz_add(a, run);
-      for (int i = 0; i < ctx->job_table_gbits; i++) a = xyzz_dbl(a);
-      xyzz_add(a, tot);
-      acc = a;
+      for (int i = 0; i < ctx->job_log_k; i++) r = xyzz_dbl(r);
+      xyzz_add(r, Y);
+      xyzz_add(r, xyzz_neg(S));  // R - S
+      for (int i = 0; i < gbits; i++) r = xyzz_dbl(r);
+      XYZZ<F> gsum = XYZZ<F>::inf();
+      for (int t = gbits - 1; t >= 0; t--) {
+        gsum = xyzz_dbl(gsum);
+        xyzz_add(gsum, BIT[log_t + t]);
+      }
+      xyzz_add(r, gsum);
+      xyzz_add(r, S);
+      acc = r;
     } else {
       acc = host_horner(rows, ctx->job_W, ctx->job_c);
     }

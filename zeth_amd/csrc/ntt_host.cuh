@@ -272,7 +272,7 @@ int ntt_inplace(zg_ctx* ctx, int curve, void* d_data, unsigned log_m, int invers
   ZG_HIP(hipMemcpyAsync(data, tmp, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   if (form == ZG_FORM_PLAIN) hipLaunchKernelGGL((k_fr_convert<Fr>), dim3(blocks), dim3(256), 0, st, data, m, 0);
   ZG_HIP(hipGetLastError());
-  ZG_HIP(hipStreamSynchronize(st));
+  ZG_HIP(zg_stream_wait(st));
   ctx->prof_end();
   return ZG_OK;
 }

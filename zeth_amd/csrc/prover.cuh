@@ -592,7 +592,7 @@ struct ProvingKeyDev : PkBase {
     if (out_form == ZG_FORM_PLAIN)
       hipLaunchKernelGGL((k_fr_convert<Fr>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, tmp, m, 0);
     ZG_HIP(hipMemcpyAsync(out, tmp, m * sizeof(Fr), hipMemcpyDeviceToHost, st));
-    ZG_HIP(hipStreamSynchronize(st));
+    ZG_HIP(zg_stream_wait(st));
     memset((char*)out + m * sizeof(Fr), 0, sizeof(Fr));
     return ZG_OK;
   }

@@ -229,6 +229,10 @@ ZG_INSTANTIATE_SELFTEST_QUAD(QuadOps32<Fp<Bn254FqParams>>, Fp<Bn254FqParams>);
 ZG_INSTANTIATE_SELFTEST_QUAD(QuadOps29<Bn254FqParams>, Fp<Bn254FqParams>);
 ZG_INSTANTIATE_SELFTEST_QUAD(QuadOps32<Fp<Bls377FqParams>>, Fp<Bls377FqParams>);
 ZG_INSTANTIATE_SELFTEST_QUAD(QuadOps29<Bls377FqParams>, Fp<Bls377FqParams>);
+using ZgSelftestFq2Bn = Fp2<Fp<Bn254FqParams>, 1>;
+using ZgSelftestFq2Bls = Fp2<Fp<Bls377FqParams>, 5>;
+ZG_INSTANTIATE_SELFTEST_QUAD(QuadOps32<ZgSelftestFq2Bn>, ZgSelftestFq2Bn);
+ZG_INSTANTIATE_SELFTEST_QUAD(QuadOps32<ZgSelftestFq2Bls>, ZgSelftestFq2Bls);
 
 #if !defined(__HIP_DEVICE_COMPILE__)  // (the host stand-ins for the lane exchanges exist in the host pass only)
 // The quad-lane point arithmetic (curve_quad.cuh, curve_quad29.cuh) with the four lanes as four host threads, against
@@ -460,6 +464,32 @@ extern "C" int zg_selftest_quad_lanes_device(int curve_group, int* mismatches) {
       int rc = check_quad_device<QuadOps32<Fp<P>>, Fp<P>>(sg, mismatches);
       if (rc == ZG_OK) rc = check_quad_device<QuadOps29<P>, Fp<P>>(sg, mismatches);
       return rc;
+    }
+    case 2: {  // the Fq2 instantiations of the same templates (32-bit limbs): the G2 combine and reduction kernels
+      using B = Fp<Bn254FqParams>;
+      using F = Fp2<B, 1>;
+      using GP = Bn254G2Params;
+      return check_quad_device<QuadOps32<F>, F>(
+          [](Affine<F>& gen) {
+            for (int k = 0; k < B::N; k++) {
+              gen.x.c0.v[k] = GP::GX_C0_MONT[k], gen.x.c1.v[k] = GP::GX_C1_MONT[k];
+              gen.y.c0.v[k] = GP::GY_C0_MONT[k], gen.y.c1.v[k] = GP::GY_C1_MONT[k];
+            }
+          },
+          mismatches);
+    }
+    case 3: {
+      using B = Fp<Bls377FqParams>;
+      using F = Fp2<B, 5>;
+      using GP = Bls377G2Params;
+      return check_quad_device<QuadOps32<F>, F>(
+          [](Affine<F>& gen) {
+            for (int k = 0; k < B::N; k++) {
+              gen.x.c0.v[k] = GP::GX_C0_MONT[k], gen.x.c1.v[k] = GP::GX_C1_MONT[k];
+              gen.y.c0.v[k] = GP::GY_C0_MONT[k], gen.y.c1.v[k] = GP::GY_C1_MONT[k];
+            }
+          },
+          mismatches);
     }
     default: return ZG_ERR_INVALID_ARGUMENT;
   }

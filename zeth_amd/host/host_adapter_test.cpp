@@ -379,7 +379,8 @@ template<typename ppT> int cmd_bench_pool(char **argv)
     const double keygen_s = std::chrono::duration<double>(clock::now() - t0).count();
     t0 = clock::now();
     device_proving_key_pool<ppT> pool(kp.pk, {0}, in_flight);
-    const Fr<ppT> r = from_hex<4>("1234567890abcdef1234567890abcdef"), s = from_hex<4>("fedcba0987654321fedcba0987654321");
+    const Fr<ppT> r = from_hex<4>("1234567890abcdef1234567890abcdef0fedcba9876543210fedcba987654321"),
+                  s = from_hex<4>("0fedcba0987654321fedcba09876543211234567890abcdef1234567890abcde");
     const typename snarkT::proof first = pool.prove(primary, auxiliary, r, s);
     const double upload_s = std::chrono::duration<double>(clock::now() - t0).count();
     {
