@@ -180,7 +180,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     tab = nullptr;
   }
   MsmPlan plan = tab ? msm_make_table_plan(n, Fr::Params::BITS, tab->c, tab->D) : msm_make_plan(n, Fr::Params::BITS, force_c);
-  if (ctx->reduce_segments && ctx->reduce_segments < plan.T) {  // fewer, longer bucket segments: less work, longer chain
+  if (!tab && ctx->reduce_segments && ctx->reduce_segments < plan.T) {  // fewer, longer bucket segments: less work, longer chain (table mode: segments cost no weighting)
     plan.T = ctx->reduce_segments;
     plan.k = plan.nb / plan.T;
   }
@@ -284,7 +284,10 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     else if (p.c == 20 && p.D == msm_table_digits(Fr::Params::BITS, 20))
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 20>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
                          (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
-    else if (p.c == 17 && p.D == msm_table_digits(Fr::Params::BITS, 17))  // (the prover's H table up to 2^19 points)
+    else if (p.c == 16 && p.D == msm_table_digits(Fr::Params::BITS, 16))
+      hipLaunchKernelGGL((k_table_scatter_static<Fr, 16>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+    else if (p.c == 17 && p.D == msm_table_digits(Fr::Params::BITS, 17))  // (the prover's tables up to 2^19 points)
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 17>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
                          (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
     else

@@ -116,6 +116,10 @@ struct ProvingKeyDev : PkBase {
   // H query as a fixed-base table (msm_table.cuh) when it is large: H then holds H_levels levels of H_len points.  The H
   // scalars are the only dense ones of a proof (uniform field elements); A, B and L are mostly 0/1 and stay windowed.
   int H_c = 0, H_levels = 0;
+  // The A, B (G1 and G2) and L queries likewise (round 3): their scalars are the witness -- mostly 0 and 1, which cost one
+  // entry each in either mode, plus the "dense" ones, which take D = 15 table digits instead of 22 windowed ones -- and
+  // one bucket set per evaluation replaces 22 windows' worth of reductions and the host's Horner over them.
+  int A_c = 0, A_levels = 0, B1_c = 0, B1_levels = 0, B2_c = 0, B2_levels = 0, L_c = 0, L_levels = 0;
   // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
   Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
   Fr z_inv;
@@ -202,43 +206,56 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(up1(&B1, v->B_g1, v->B_len));
     ZG_TRY(up1(&H, v->H_query, v->H_len));
     ZG_TRY(up1(&L, v->L_query, v->L_len));
+    // ZG_PK_TABLE_MIN: smallest domain whose queries get fixed-base tables (default 2^18: a JoinSplit-scale proof, domain
+    // 2^19, takes 5.15 ms with the H table and 5.5 ms without; 0 = never)
+    const char* e_min = getenv("ZG_PK_TABLE_MIN");
+    const size_t table_min = e_min ? strtoull(e_min, nullptr, 0) : ((size_t)1 << 18);
+    const bool want_tables = table_min && v->H_len + 1 >= table_min;  // H_len = domain size - 1
+    // replaces *pts (len points) by a table of D levels when there is room for it; the plain query proves just as well
+    auto make_table = [&](const GroupOps* o, void** pts, size_t len, size_t point_bytes, int want_c, int* c_out, int* D_out) -> int {
+      if (!want_tables || len < 1024) return ZG_OK;
+      int c = 0, D = 0;
+      ZG_TRY(o->table_params(len, want_c, &c, &D));
+      if ((uint64_t)D * len >= (1ull << 31)) return ZG_OK;
+      void* table = nullptr;
+      if (hipMalloc(&table, (size_t)D * len * point_bytes) != hipSuccess) {
+        (void)hipGetLastError();  // no room for the table
+        return ZG_OK;
+      }
+      ZG_HIP(hipMemcpyAsync(table, *pts, len * point_bytes, hipMemcpyDeviceToDevice, st));
+      const int s = o->table_build(ctx, table, len, c, D);
+      if (s != ZG_OK) {
+        hipFree(table);
+        return s;
+      }
+      hipFree(*pts);
+      *pts = table;
+      *c_out = c;
+      *D_out = D;
+      return ZG_OK;
+    };
     {
-      // ZG_PK_TABLE_MIN: smallest domain whose H query gets a table (default 2^18, i.e. 2^18 - 1 points: a JoinSplit-scale proof, H of 2^19 - 1
-      // points, takes 5.15 ms with it and 5.5 ms without; 0 = never)
-      const char* e = getenv("ZG_PK_TABLE_MIN");
-      const size_t table_min = e ? strtoull(e, nullptr, 0) : ((size_t)1 << 18);
-      if (table_min && v->H_len + 1 >= table_min && v->H_len >= 1024) {  // H_len = domain size - 1
-        int c = 0, D = 0;
-        static const int h_table_c = zg_knob("ZG_PK_TABLE_C") ? atoi(zg_knob("ZG_PK_TABLE_C")) : 0;  // tuning knob
-        // Up to 2^19 points a 17-bit table (15 digits, 2^16 buckets in two groups) instead of the lone evaluation's 20 bits:
-        // alone the two take the same time, inside a proof the eight times smaller reduction leaves the device to the
-        // other evaluations (JoinSplit shape, four proofs in flight: 375 -> 385-398 proofs/s, latency unchanged).  From
-        // 2^20 points on 20 bits win alone and inside a proof (BLS12-377, 2^20 constraints: 11.9 against 12.9 ms).
-        const int want_c = h_table_c ? h_table_c : (v->H_len < ((size_t)1 << 19) ? 17 : 0);
-        ZG_TRY(o1->table_params(v->H_len, want_c, &c, &D));
-        if ((uint64_t)D * v->H_len < (1ull << 31)) {
-          Affine<Fq>* table = nullptr;
-          if (hipMalloc((void**)&table, (size_t)D * v->H_len * sizeof(Affine<Fq>)) != hipSuccess) {
-            (void)hipGetLastError();  // no room for the table: the plain H query is resident and proves just as well
-            table = nullptr;
-          }
-          if (table) {
-            ZG_HIP(hipMemcpyAsync(table, H, v->H_len * sizeof(Affine<Fq>), hipMemcpyDeviceToDevice, st));
-            int s = o1->table_build(ctx, table, v->H_len, c, D);
-            if (s != ZG_OK) {
-              hipFree(table);
-              return s;
-            }
-            hipFree(H);
-            H = table;
-            H_c = c;
-            H_levels = D;
-          }
-        }
+      static const int h_table_c = zg_knob("ZG_PK_TABLE_C") ? atoi(zg_knob("ZG_PK_TABLE_C")) : 0;  // tuning knob
+      // Up to 2^19 points a 17-bit table (15 digits, 2^16 buckets in two groups) instead of the lone evaluation's 20 bits:
+      // alone the two take the same time, inside a proof the eight times smaller reduction leaves the device to the
+      // other evaluations (JoinSplit shape, four proofs in flight: 375 -> 385-398 proofs/s, latency unchanged).  From
+      // 2^20 points on 20 bits win alone and inside a proof (BLS12-377, 2^20 constraints: 11.9 against 12.9 ms).
+      const int want_c = h_table_c ? h_table_c : (v->H_len < ((size_t)1 << 19) ? 17 : 0);
+      ZG_TRY(make_table(o1, (void**)&H, v->H_len, sizeof(Affine<Fq>), want_c, &H_c, &H_levels));
+      // the witness queries: 17 bits (tuning knob ZG_PK_LANE_TABLE_C; 0 there = no tables for them)
+      static const int lane_table_c = zg_knob("ZG_PK_LANE_TABLE_C") ? atoi(zg_knob("ZG_PK_LANE_TABLE_C")) : 17;
+      if (lane_table_c) {
+        ZG_TRY(make_table(o1, (void**)&A, v->A_len, sizeof(Affine<Fq>), lane_table_c, &A_c, &A_levels));
+        ZG_TRY(make_table(o1, (void**)&B1, v->B_len, sizeof(Affine<Fq>), lane_table_c, &B1_c, &B1_levels));
+        ZG_TRY(make_table(o1, (void**)&L, v->L_len, sizeof(Affine<Fq>), lane_table_c, &L_c, &L_levels));
       }
     }
     ZG_TRY(dev_copy(&B2, v->B_g2, v->B_len));
     if (plain && v->B_len) ZG_TRY(o2->to_mont(ctx, B2, v->B_len));
+    {
+      static const int lane_table_c = zg_knob("ZG_PK_LANE_TABLE_C") ? atoi(zg_knob("ZG_PK_LANE_TABLE_C")) : 17;
+      if (lane_table_c) ZG_TRY(make_table(o2, (void**)&B2, v->B_len, sizeof(Affine<Fq2T>), lane_table_c, &B2_c, &B2_levels));
+    }
     for (size_t i = 0; i < v->B_len; i++)
       if (v->B_indices[i] > num_vars) return ZG_ERR_INVALID_ARGUMENT;
     ZG_TRY(dev_copy(&B_idx, v->B_indices, v->B_len));
@@ -310,6 +327,8 @@ struct ProvingKeyDev : PkBase {
     p->A = A; p->B1 = B1; p->H = H; p->L = L; p->B2 = B2; p->B_idx = B_idx;
     p->A_len = A_len; p->B_len = B_len; p->H_len = H_len; p->L_len = L_len;
     p->H_c = H_c; p->H_levels = H_levels;
+    p->A_c = A_c; p->A_levels = A_levels; p->B1_c = B1_c; p->B1_levels = B1_levels;
+    p->B2_c = B2_c; p->B2_levels = B2_levels; p->L_c = L_c; p->L_levels = L_levels;
     int s = p->alloc_scratch();
     if (s == ZG_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = ZG_ERR_HIP;
     if (s != ZG_OK) {
@@ -442,11 +461,15 @@ struct ProvingKeyDev : PkBase {
         lane[i]->job_n = 0;
         return;
       }
+      // (a query that has a table is evaluated over it: the window width is the table's, and the hint plays no part)
+      const MsmTable tabs[4] = {{B_len, 0, B2_c, B2_levels}, {A_len, 0, A_c, A_levels}, {L_len, 0, L_c, L_levels}, {B_len, 0, B1_c, B1_levels}};
+      const MsmTable* tab = tabs[i].D ? &tabs[i] : nullptr;
+      const int c = tab ? 0 : width(dense_hint[i]);
       switch (i) {
-        case 0: lane_status[0] = o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, width(dense_hint[0]), nullptr); break;
-        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, width(dense_hint[1]), nullptr); break;
-        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, width(dense_hint[2]), nullptr); break;
-        default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, width(dense_hint[3]), nullptr); break;
+        case 0: lane_status[0] = o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, c, tab); break;
+        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, c, tab); break;
+        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, c, tab); break;
+        default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, c, tab); break;
       }
     };
     static const bool serial_queue = zg_knob("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
