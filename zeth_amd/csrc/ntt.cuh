@@ -58,6 +58,16 @@ struct NttTables {
   const uint32_t* g_hi29;
   Fr m_inv;
   unsigned log_n1, log_n2;
+  // Full-size tables (round 3; null: the two-level forms above are used -- the allocation-free entry point, whose static
+  // scratch has no room for them).  The transforms are bound by the field multiplier, not by memory, so every place that
+  // built a factor from two small tables with two products now reads it from an m-entry table laid out like the data
+  // (coalesced, 32 bytes an element) and pays one: the inter-pass twiddle, the coset input and the coset output.
+  const Fr* twf;      // [k1][col] = w^(col k1), stored form: the inter-pass twiddle of pass A
+  const Fr* twf_inv;  // the same for w^-1
+  const Fr* in_tab;   // [j] = g^j R' (the stored form of 32 g^j): the coset input scaling of pass A
+  const Fr* out_tab;  // [j] = the factor of output j in the stored form, OUT_MODE 3 of pass B (set per launch: g^-j m^-1
+                      //       for icosetFFT, or g^j m^-1 for an iFFT whose result feeds a coset FFT)
+  Fr qap_c;           // QAP_IN: 1024 / Z(g) in the stored form (see k_ntt_pass_a)
 };
 
 template <class Fr>
@@ -275,27 +285,42 @@ __device__ __forceinline__ uint32_t ntt_tile_of_block(uint32_t b, uint32_t nbloc
   return ((slot / share) * 8u + xcd) * share + (slot % share);
 }
 
-// pass A: grid = (N2 / TC, batch) blocks, TC = 2^log_tc adjacent columns per tile
-template <class Fr, bool COSET_IN, int RMAX>
+// pass A: grid = (N2 / TC, batch) blocks, TC = 2^log_tc adjacent columns per tile.
+// IN_MODE 0: the vector as it is; 1: coset input, x g^j; 2 ("QAP_IN", batch 1): the element is built from THREE vectors
+// a, a + vstride, a + 2 vstride (the evaluations of A, B, C on the coset) as (A B - C) / Z(g) -- the pointwise step of
+// r1cs_to_qap_witness_map between the coset FFTs and the final icosetFFT, which used to be a kernel of its own
+// (read three vectors, write one).  The result of the pass is written over the first vector.
+template <class Fr, int IN_MODE, int RMAX>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, NttTables<Fr> T, int inverse, unsigned log_tc,
                                                             size_t vstride) {
+  constexpr bool COSET_IN = IN_MODE == 1;
+  constexpr bool QAP_IN = IN_MODE == 2;
   extern __shared__ uint32_t lds[];
   using N = Ntt29<Fr>;
   using P = typename N::P;
   constexpr uint32_t PER = 1u << RMAX;
-  a += (size_t)blockIdx.y * vstride;
+  if (!QAP_IN) a += (size_t)blockIdx.y * vstride;
   const uint32_t N2 = 1u << T.log_n2;
   const Fr* tw = inverse ? T.tw_inv : T.tw;
+  const Fr* twf = inverse ? T.twf_inv : T.twf;
   const uint32_t* tw29 = inverse ? T.twa_inv29 : T.twa29;
   const uint32_t c0 = ntt_tile_of_block(blockIdx.x, gridDim.x, log_tc) << log_tc;
   const uint32_t total = 1u << (T.log_n1 + log_tc);
   const uint32_t cmask = (1u << log_tc) - 1u;
   for (uint32_t i0 = threadIdx.x; i0 < total; i0 += PER * blockDim.x) {
     Fr x[PER];
+    Fr xb[QAP_IN ? PER : 1], xc[QAP_IN ? PER : 1];
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
       const uint32_t idx = i0 + k * blockDim.x;
-      if (idx < total) x[k] = glob_get(a + (size_t)(idx >> log_tc) * N2 + c0 + (idx & cmask));
+      if (idx < total) {
+        const size_t at = (size_t)(idx >> log_tc) * N2 + c0 + (idx & cmask);
+        x[k] = glob_get(a + at);
+        if constexpr (QAP_IN) {
+          xb[k] = glob_get(a + vstride + at);
+          xc[k] = glob_get(a + 2 * vstride + at);
+        }
+      }
     }
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
@@ -303,7 +328,18 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, 
       if (idx < total) {
         const uint32_t j1 = idx >> log_tc, c = idx & cmask;
         const uint32_t pos = (bitrev32(j1, T.log_n1) << log_tc) + c;
-        if (COSET_IN) {
+        if constexpr (QAP_IN) {
+          // a R (as it is) against b R' (shifted read): a b R, below 2 p; minus c R; against the stored 1024 / Z: the product
+          // lands on ((a b - c) / Z) 32 R = h R', the form the rounds work in
+          const auto t = f29::mul(f29::unpack_raw(x[k]), f29::unpack(xb[k]));
+          const auto u = f29::carry(f29::sub(t, f29::unpack_raw(xc[k])));
+          const auto h = f29::mul(u, f29::unpack_raw(T.qap_c));
+          lds_put29(lds, pos, f29::widen<N::X0::vb, N::X0::lmax>(h));
+        } else if (COSET_IN && T.in_tab) {
+          // x R' against the table's g^j R': x g^j R', below 2 p
+          const auto u = f29::mul(f29::unpack(x[k]), f29::unpack_raw(glob_get(T.in_tab + (size_t)j1 * N2 + c0 + c)));
+          lds_put29(lds, pos, f29::widen<N::X0::vb, N::X0::lmax>(u));
+        } else if (COSET_IN) {
           // x R' g_hi R' / R' = x g_hi R' (< 2 p), then against g_lo R' (< 32 p): x g R' < 2 p
           const auto t = f29::mul(f29::unpack(x[k]), tw_get29<Fr>(T.g_hi29, j1));
           const auto u = f29::mul(t, f29::unpack(glob_get(T.g_lo + c0 + c)));
@@ -325,7 +361,10 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, 
     // sign), then against the STORED w^e_lo R, which lands the product in the stored form (R mod p when there is no
     // twiddle).
     typename N::W r;
-    if (e != 0 && N2 > 1) {
+    if (twf) {
+      // one product against the stored w^(col k1) (1 for the first row and column): the result is in the stored form
+      r = f29::canon(f29::mul(x, f29::unpack_raw(glob_get(twf + (size_t)k1 * N2 + c0 + c))));
+    } else if (e != 0 && N2 > 1) {
       const uint32_t e_hi = e >> T.log_n2, e_lo = e & (N2 - 1u), hn1 = (1u << T.log_n1) >> 1;
       const auto t = f29::mul(x, tw_get29<Fr>(tw29, e_hi & (hn1 - 1u)));
       r = f29::canon(f29::mul(t, f29::unpack_raw(glob_get(tw + e_lo))));
@@ -338,7 +377,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, 
 }
 
 // pass B: grid = (N1 / TR, batch) blocks, TR = 2^log_tr adjacent rows per tile.  OUT_MODE 0: none, 1: * m^-1,
-// 2: * g^-k m^-1 (two-level tables)
+// 2: * g^-k m^-1 (two-level tables), 3: * out_tab[k] (full table, one product)
 template <class Fr, int OUT_MODE, int RMAX>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const Fr* __restrict__ a, Fr* __restrict__ out, NttTables<Fr> T,
                                                             int inverse, unsigned log_tr, size_t vstride) {
@@ -374,6 +413,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const Fr* __restrict
     typename N::W y;
     if (OUT_MODE == 0) y = f29::canon(f29::mul(x, f29::r_conv<P>()));
     if (OUT_MODE == 1) y = f29::canon(f29::mul(x, f29::unpack_raw(T.m_inv)));
+    if (OUT_MODE == 3) y = f29::canon(f29::mul(x, f29::unpack_raw(glob_get(T.out_tab + (size_t)k2 * N1 + r0 + r))));
     if (OUT_MODE == 2)  // x R' against the stored gi_lo R: x gi_lo R (< 2 p); that against gi_hi R' (< 32 p): x gi R
       y = f29::canon(f29::mul(f29::mul(x, f29::unpack_raw(glob_get(T.gi_lo + r0 + r))), f29::unpack(glob_get(T.gi_hi + k2))));
     glob_put(out + (size_t)k2 * N1 + r0 + r, f29::to_words(y));
@@ -394,6 +434,20 @@ __global__ void __launch_bounds__(256) k_to_radix29(const Fr* __restrict__ src, 
 }
 
 // ---- table construction -------------------------------------------------------------------------
+// twf[k1 * N2 + col] = w^(col k1) from the half table tw[i] = w^i, i < m/2 (w^(m/2) = -1)
+template <class Fr>
+__global__ void __launch_bounds__(256) k_twf_fill(const Fr* __restrict__ tw, unsigned log_m, unsigned log_n2, Fr* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t m = (size_t)1 << log_m;
+  if (idx >= m) return;
+  const size_t k1 = idx >> log_n2, col = idx & (((size_t)1 << log_n2) - 1);
+  const size_t e = (k1 * col) & (m - 1);
+  const size_t half = m > 1 ? m / 2 : 1;
+  Fr v = glob_get(tw + (e < half ? e : e - half));
+  if (e >= half && m > 1) v = Fr::neg(v);
+  glob_put(out + idx, v);
+}
+
 // out[i] = base^(i * step) * scale, i < count
 template <class Fr>
 __global__ void __launch_bounds__(256) k_pow_table(Fr* __restrict__ out, Fr base, uint64_t step, Fr scale, uint32_t count) {

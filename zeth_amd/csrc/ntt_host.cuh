@@ -14,11 +14,21 @@ template <class Fr>
 struct NttDomain : NttDomainBase {
   NttTables<Fr> T;
   Fr* storage = nullptr;
+  // the full-size tables (ntt.cuh, NttTables::twf ...): five vectors of m elements in one allocation -- twf, twf_inv,
+  // in_tab, then the two output tables g^-j m^-1 (icosetFFT) and g^j m^-1 (an iFFT feeding a coset FFT); null when the
+  // memory could not be had or the domain lives in the static scratch (the two-level forms serve then)
+  Fr* full = nullptr;
+  const Fr *out_icoset = nullptr, *out_fuse = nullptr;
   uint32_t TC = 1, TR = 1;
   ~NttDomain() override {
     if (storage) hipFree(storage);
+    if (full) hipFree(full);
   }
 };
+
+// launch flags of ntt_launch
+static constexpr int NTT_FUSE_COSET_NEXT = 1;  // iFFT only: outputs are also scaled by g^j -- the following transform is a plain FFT
+static constexpr int NTT_QAP_IN = 2;           // icosetFFT only: the input is (A B - C) / Z(g) of three vectors (k_ntt_pass_a)
 
 template <class Fr>
 inline Fr fr_from_limbs(const uint32_t* l) {
@@ -147,6 +157,8 @@ int ntt_fill_tables(zg_ctx* ctx, unsigned log_m, Fr* storage, NttDomain<Fr>* D, 
   D->T.twb_inv29 = twbi29;
   D->T.g_hi29 = g_hi29;
   D->T.m_inv = minv;
+  D->T.twf = D->T.twf_inv = D->T.in_tab = D->T.out_tab = nullptr;
+  D->T.qap_c = Fr::zero();
   D->T.log_n1 = l1;
   D->T.log_n2 = l2;
   D->TC = ntt_pick_tile(N1, N2);
@@ -172,6 +184,40 @@ int ntt_get_domain(zg_ctx* ctx, int curve, unsigned log_m, NttDomain<Fr>** out) 
     return e == hipErrorOutOfMemory ? ZG_ERR_OUT_OF_MEMORY : ZG_ERR_HIP;
   }
   int s = ntt_fill_tables<Fr>(ctx, log_m, D->storage, D);
+  if (s == ZG_OK) {
+    const size_t m = (size_t)1 << log_m;
+    if (hipMalloc((void**)&D->full, 5 * m * sizeof(Fr)) != hipSuccess) {
+      (void)hipGetLastError();  // no room: the two-level tables serve
+      D->full = nullptr;
+    } else {
+      using P = typename Fr::Params;
+      Fr* twf = D->full;
+      Fr* twfi = twf + m;
+      Fr* in_tab = twfi + m;
+      Fr* out_ic = in_tab + m;
+      Fr* out_fu = out_ic + m;
+      hipStream_t st = ctx->stream;
+      const unsigned blocks = (unsigned)((m + 255) / 256);
+      hipLaunchKernelGGL((k_twf_fill<Fr>), dim3(blocks), dim3(256), 0, st, D->T.tw, log_m, D->T.log_n2, twf);
+      hipLaunchKernelGGL((k_twf_fill<Fr>), dim3(blocks), dim3(256), 0, st, D->T.tw_inv, log_m, D->T.log_n2, twfi);
+      const Fr g = fr_from_limbs<Fr>(P::GEN_MONT), gi = fr_from_limbs<Fr>(P::GEN_INV_MONT);
+      Fr thirty_two = Fr::zero();
+      thirty_two.v[0] = 32;
+      hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, st, in_tab, g, (uint64_t)1, Fr::to_mont(thirty_two), (uint32_t)m);
+      hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, st, out_ic, gi, (uint64_t)1, D->T.m_inv, (uint32_t)m);
+      hipLaunchKernelGGL((k_pow_table<Fr>), dim3(blocks), dim3(256), 0, st, out_fu, g, (uint64_t)1, D->T.m_inv, (uint32_t)m);
+      if (hipGetLastError() != hipSuccess) s = ZG_ERR_HIP;
+      D->T.twf = twf;
+      D->T.twf_inv = twfi;
+      D->T.in_tab = in_tab;
+      D->out_icoset = out_ic;
+      D->out_fuse = out_fu;
+      // 1024 / Z(g), Z(g) = g^m - 1 (divide_by_Z_on_coset), for the QAP_IN load
+      Fr k1024 = Fr::zero();
+      k1024.v[0] = 1024;
+      D->T.qap_c = Fr::mul(Fr::to_mont(k1024), Fr::inv(Fr::sub(host_pow_u64(g, (uint64_t)m), Fr::one())));
+    }
+  }
   if (s == ZG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = ZG_ERR_HIP;
   if (s != ZG_OK) {
     delete D;
@@ -189,18 +235,22 @@ inline unsigned ilog2_u32(uint32_t x) {
 }
 
 template <class Fr, int RMAX>
-int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset, unsigned batch, size_t vstride) {
+int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset, unsigned batch, size_t vstride, int flags) {
   static std::once_flag attr_once;  // clones of a key prove from several threads (zg_pk_clone)
   hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
     const int lim = NTT_LDS_SLOTS * 36;
-    const void* kernels[] = {(const void*)k_ntt_pass_a<Fr, false, RMAX>, (const void*)k_ntt_pass_a<Fr, true, RMAX>,
+    const void* kernels[] = {(const void*)k_ntt_pass_a<Fr, 0, RMAX>, (const void*)k_ntt_pass_a<Fr, 1, RMAX>,
+                             (const void*)k_ntt_pass_a<Fr, 2, RMAX>,
                              (const void*)k_ntt_pass_b<Fr, 0, RMAX>, (const void*)k_ntt_pass_b<Fr, 1, RMAX>,
-                             (const void*)k_ntt_pass_b<Fr, 2, RMAX>};
+                             (const void*)k_ntt_pass_b<Fr, 2, RMAX>, (const void*)k_ntt_pass_b<Fr, 3, RMAX>};
     for (const void* k : kernels)
       if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   });
   ZG_HIP(attr_err);
+  const bool fuse_next = (flags & NTT_FUSE_COSET_NEXT) != 0, qap_in = (flags & NTT_QAP_IN) != 0;
+  if ((fuse_next && (!inverse || coset)) || (qap_in && (!inverse || !coset || batch != 1)) || ((fuse_next || qap_in) && !D->full))
+    return ZG_ERR_INVALID_ARGUMENT;
   const uint32_t N1 = 1u << D->T.log_n1, N2 = 1u << D->T.log_n2;
   const uint32_t TC = D->TC, TR = D->TR;
   const unsigned log_tc = ilog2_u32(TC), log_tr = ilog2_u32(TR);
@@ -213,20 +263,27 @@ int ntt_launch_r(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, 
     if (t > (uint32_t)ntt_max_threads(RMAX)) t = ntt_max_threads(RMAX);
     return t;
   };
+  NttTables<Fr> T = D->T;
   ctx->mark("ntt_pass_a");
   const dim3 ga(N2 / TC, batch), ta(threads(N1 * TC));
-  if (coset && !inverse)
-    hipLaunchKernelGGL((k_ntt_pass_a<Fr, true, RMAX>), ga, ta, lds_a, st, data, D->T, inverse, log_tc, vstride);
+  if (qap_in)
+    hipLaunchKernelGGL((k_ntt_pass_a<Fr, 2, RMAX>), ga, ta, lds_a, st, data, T, inverse, log_tc, vstride);
+  else if (coset && !inverse)
+    hipLaunchKernelGGL((k_ntt_pass_a<Fr, 1, RMAX>), ga, ta, lds_a, st, data, T, inverse, log_tc, vstride);
   else
-    hipLaunchKernelGGL((k_ntt_pass_a<Fr, false, RMAX>), ga, ta, lds_a, st, data, D->T, inverse, log_tc, vstride);
+    hipLaunchKernelGGL((k_ntt_pass_a<Fr, 0, RMAX>), ga, ta, lds_a, st, data, T, inverse, log_tc, vstride);
   ctx->mark("ntt_pass_b");
   const dim3 gb(N1 / TR, batch), tb(threads(N2 * TR));
-  if (!inverse)
-    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 0, RMAX>), gb, tb, lds_b, st, data, out, D->T, inverse, log_tr, vstride);
-  else if (!coset)
-    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 1, RMAX>), gb, tb, lds_b, st, data, out, D->T, inverse, log_tr, vstride);
-  else
-    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 2, RMAX>), gb, tb, lds_b, st, data, out, D->T, inverse, log_tr, vstride);
+  if (!inverse) {
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 0, RMAX>), gb, tb, lds_b, st, data, out, T, inverse, log_tr, vstride);
+  } else if (!coset && !fuse_next) {
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 1, RMAX>), gb, tb, lds_b, st, data, out, T, inverse, log_tr, vstride);
+  } else if (D->full) {
+    T.out_tab = coset ? D->out_icoset : D->out_fuse;
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 3, RMAX>), gb, tb, lds_b, st, data, out, T, inverse, log_tr, vstride);
+  } else {
+    hipLaunchKernelGGL((k_ntt_pass_b<Fr, 2, RMAX>), gb, tb, lds_b, st, data, out, T, inverse, log_tr, vstride);
+  }
   ctx->mark("ntt_end");
   ZG_HIP(hipGetLastError());
   return ZG_OK;
@@ -248,10 +305,11 @@ inline int ntt_pick_rmax(size_t total_elems) {
 // data (`batch` vectors of m elements, `vstride` elements apart, Montgomery form) is overwritten with pass A's
 // intermediate; the transforms land in `out` (same layout).
 template <class Fr>
-int ntt_launch(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset, unsigned batch = 1, size_t vstride = 0) {
+int ntt_launch(zg_ctx* ctx, NttDomain<Fr>* D, Fr* data, Fr* out, int inverse, int coset, unsigned batch = 1, size_t vstride = 0,
+               int flags = 0) {
   const int r = ntt_pick_rmax(((size_t)batch) << D->T.log_m);
-  if (r == 2) return ntt_launch_r<Fr, 2>(ctx, D, data, out, inverse, coset, batch, vstride);
-  return ntt_launch_r<Fr, 1>(ctx, D, data, out, inverse, coset, batch, vstride);
+  if (r == 2) return ntt_launch_r<Fr, 2>(ctx, D, data, out, inverse, coset, batch, vstride, flags);
+  return ntt_launch_r<Fr, 1>(ctx, D, data, out, inverse, coset, batch, vstride, flags);
 }
 
 // C-ABI level: in-place semantics on `data` (device pointer, Montgomery or plain per `form`)

@@ -365,6 +365,10 @@ struct ProvingKeyDev : PkBase {
     const unsigned mb = (unsigned)((m + 255) / 256);
     NttDomain<Fr>* D = nullptr;
     ZG_TRY(ntt_get_domain<Fr>(ctx, curve, log_m, &D));
+    // With the domain's full-size tables (ntt_host.cuh) the chain is: iFFT whose output scaling also carries g^j, a PLAIN
+    // FFT (that is the coset FFT then), and an icosetFFT whose load builds (A B - C) / Z(g) from the three vectors -- two
+    // products per element fewer in each of the three coset FFTs, and no pointwise kernel.  Without them: the separate steps.
+    const bool fused = D->full != nullptr;
     if (first_part <= 0 && last_part >= 0) {
       SpmvMatrices M;
       for (int k = 0; k < 3; k++) {
@@ -373,12 +377,16 @@ struct ProvingKeyDev : PkBase {
         M.val[k] = mat[k].val;
       }
       hipLaunchKernelGGL((k_spmv<Fr>), dim3(mb, 3), dim3(256), 0, st, M, (const Fr*)w, nc, m, num_inputs + 1, ev[0]);
-      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 0, 3, m));  // iFFT of A, B, C
+      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 0, 3, m, fused ? NTT_FUSE_COSET_NEXT : 0));  // iFFT of A, B, C
     }
-    if (first_part <= 1 && last_part >= 1) ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[0], 0, 1, 3, m));  // cosetFFT of A, B, C
+    if (first_part <= 1 && last_part >= 1) ZG_TRY(ntt_launch<Fr>(ctx, D, tmp, ev[0], 0, fused ? 0 : 1, 3, m));  // cosetFFT of A, B, C
     if (first_part <= 2 && last_part >= 2) {
-      hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
-      ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
+      if (fused) {
+        ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1, 1, m, NTT_QAP_IN));  // (A B - C) / Z, icosetFFT
+      } else {
+        hipLaunchKernelGGL((k_h_pointwise<Fr>), dim3(mb), dim3(256), 0, st, ev[0], ev[1], ev[2], z_inv, m);
+        ZG_TRY(ntt_launch<Fr>(ctx, D, ev[0], tmp, 1, 1));  // icosetFFT
+      }
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
