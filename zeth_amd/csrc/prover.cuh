@@ -15,6 +15,9 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <system_error>
 #include <thread>
 
@@ -22,6 +25,73 @@
 #include "ntt_host.cuh"
 
 namespace zg {
+
+// A host thread that lives as long as its prover and runs one job at a time: a proof hands each of its four lanes'
+// queueing (and, for large assignments, a slice of the upload) to one.  Creating four threads per proof cost the calling
+// thread ~0.1 ms of every proof; when a thread cannot be had the job runs on the caller.
+class LaneWorker {
+ public:
+  LaneWorker() {
+    try {
+      th_ = std::thread([this] { loop(); });
+    } catch (const std::system_error&) {
+    }
+  }
+  ~LaneWorker() {
+    if (th_.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = true;
+      }
+      cv_.notify_all();
+      th_.join();
+    }
+  }
+  LaneWorker(const LaneWorker&) = delete;
+  void submit(std::function<void()> job) {
+    if (!th_.joinable()) {
+      job();
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = std::move(job);
+      has_job_ = true;
+      done_ = false;
+    }
+    cv_.notify_all();
+  }
+  void wait() {
+    if (!th_.joinable()) return;
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return done_; });
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::function<void()> j;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return has_job_ || stop_; });
+        if (!has_job_) return;
+        j = std::move(job_);
+        has_job_ = false;
+      }
+      j();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        done_ = true;
+      }
+      cv_.notify_all();
+    }
+  }
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool has_job_ = false, done_ = true, stop_ = false;
+};
 
 struct CsrDev {
   uint64_t* row_ptr = nullptr;
@@ -124,6 +194,11 @@ struct ProvingKeyDev : PkBase {
   Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
   Fr z_inv;
   zg_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
+  LaneWorker* worker[4] = {nullptr, nullptr, nullptr, nullptr};
+  // page-locked staging of the parallel upload: two halves per lane, and the events that say a half's copy has left it
+  static constexpr size_t STAGE_BYTES = (size_t)2 << 20;
+  char* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   uint32_t dense_hint[4] = {0, 0, 0, 0};
   hipEvent_t w_ready = nullptr;
   bool owns_key = true;  // false for a clone: bases and matrices belong to the key it was cloned from
@@ -131,6 +206,12 @@ struct ProvingKeyDev : PkBase {
   ~ProvingKeyDev() override {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (auto& wk : worker) delete wk;  // (joins the thread)
+    for (int i = 0; i < 4; i++) {
+      if (stage[i]) hipHostFree(stage[i]);
+      for (auto& e : stage_ev[i])
+        if (e) hipEventDestroy(e);
+    }
     for (auto& l : lane)
       if (l) zg_ctx_destroy(l);
     if (w_ready) hipEventDestroy(w_ready);
@@ -296,6 +377,13 @@ struct ProvingKeyDev : PkBase {
        // rounds 1 and 2) a proof does not complete within 90 s: no fault, the process stays killable, and with equal
        // priorities the same queue of work takes 4 ms -- the lanes' queues are not served while the high-priority queue
        // exists, even when it is idle.  Cause inside the runtime's queue scheduling not found; not pursued.
+    for (int i = 0; i < 4; i++) {
+      worker[i] = new LaneWorker();
+      if ((num_vars * sizeof(Fr)) >= PAR_UPLOAD_MIN) {
+        ZG_HIP(hipHostMalloc((void**)&stage[i], 2 * STAGE_BYTES, hipHostMallocDefault));
+        for (auto& e : stage_ev[i]) ZG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+    }
     ZG_HIP(hipEventCreateWithFlags(&w_ready, hipEventDisableTiming));
     ZG_HIP(hipMalloc((void**)&w, (num_vars + 1) * sizeof(Fr)));
     // the three evaluation vectors are one allocation, m elements apart, and so is the transform buffer: the transforms
@@ -346,12 +434,51 @@ struct ProvingKeyDev : PkBase {
     return qap_h();
   }
 
+  // Assignments of this size or more are uploaded by the four lane threads, a quarter each, through page-locked staging:
+  // the runtime's own path for pageable memory reaches ~29 GB/s (BLS12-377, 2^22 constraints: 168 MB, 5.8 of 33 ms with
+  // nothing else able to start), four copying threads with their transfers in flight reach 53 GB/s (3.2 ms).  Not below
+  // 32 MB: a JoinSplit-sized assignment (17.5 MB) gains 0.1 ms alone and loses 8 % of the throughput with four proofs in
+  // flight (sixteen copying threads on the box's cores).
+  static constexpr size_t PAR_UPLOAD_MIN = (size_t)32 << 20;
+
+  // lane i's share of the upload: src -> staging halves -> dst, the copy of one half in flight while the other is filled
+  int upload_slice(int i, char* dst, const char* src, size_t bytes) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return ZG_ERR_HIP;
+    hipStream_t ls = lane[i]->stream;
+    size_t k = 0;
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES, k++) {
+      const size_t len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+      const int h = (int)(k & 1);
+      if (k >= 2) ZG_HIP(hipEventSynchronize(stage_ev[i][h]));
+      memcpy(stage[i] + h * STAGE_BYTES, src + off, len);
+      ZG_HIP(hipMemcpyAsync(dst + off, stage[i] + h * STAGE_BYTES, len, hipMemcpyHostToDevice, ls));
+      ZG_HIP(hipEventRecord(stage_ev[i][h], ls));
+    }
+    ZG_HIP(hipStreamSynchronize(ls));
+    return ZG_OK;
+  }
+
   // 1 || w in Montgomery form on the device
   int load_assignment(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form) {
     if (n_primary != num_inputs || n_primary + n_aux != num_vars) return ZG_ERR_INVALID_ARGUMENT;
     hipStream_t st = ctx->stream;
     if (n_primary) ZG_HIP(hipMemcpyAsync(assign, primary, n_primary * sizeof(Fr), hipMemcpyHostToDevice, st));
-    if (n_aux) ZG_HIP(hipMemcpyAsync(assign + n_primary, aux, n_aux * sizeof(Fr), hipMemcpyHostToDevice, st));
+    const size_t aux_bytes = n_aux * sizeof(Fr);
+    static const bool no_par_upload = zg_knob("ZG_PROVE_NO_PAR_UPLOAD") != nullptr;  // measurement knob
+    if (aux_bytes >= PAR_UPLOAD_MIN && stage[0] && !no_par_upload) {
+      int status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
+      const size_t per = ((aux_bytes / 4) + 255) & ~(size_t)255;
+      for (int i = 0; i < 4; i++) {
+        const size_t lo = per * i < aux_bytes ? per * i : aux_bytes, hi = lo + per < aux_bytes ? lo + per : aux_bytes;
+        char* dst = reinterpret_cast<char*>(assign + n_primary) + lo;
+        const char* src = static_cast<const char*>(aux) + lo;
+        worker[i]->submit([this, i, dst, src, lo, hi, &status] { status[i] = upload_slice(i, dst, src, hi - lo); });
+      }
+      for (int i = 0; i < 4; i++) worker[i]->wait();
+      for (int i = 0; i < 4; i++) ZG_TRY(status[i]);
+    } else if (n_aux) {
+      ZG_HIP(hipMemcpyAsync(assign + n_primary, aux, aux_bytes, hipMemcpyHostToDevice, st));
+    }
     hipLaunchKernelGGL((k_build_w<Fr>), dim3((unsigned)((num_vars + 1 + 255) / 256)), dim3(256), 0, st, assign, n_primary,
                        assign + n_primary, n_aux, form == ZG_FORM_PLAIN, w);
     return ZG_OK;
@@ -481,21 +608,16 @@ struct ProvingKeyDev : PkBase {
       }
     };
     static const bool serial_queue = zg_knob("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
-    std::thread workers[4];
-    // the head of the longest chain is queued before the lanes' threads are started (their creation is ~0.1 ms of this
-    // thread's time, during which the device would have nothing of the H chain to run)
+    // the head of the longest chain is queued before the lanes' jobs are handed out
     const bool head_first = h_status == ZG_OK && hold == 0;
     ZG_CRUMB("prove: qap_h head");
     if (head_first) h_status = qap_h(0, 0);
     ZG_CRUMB("prove: starting lane threads");
-    if (!serial_queue) {
-      for (int i = 0; i < 4; i++) {
-        try {
-          workers[i] = std::thread(queue_lane, i);
-        } catch (const std::system_error&) {
-          // no thread to be had: this lane is queued by the calling thread below (no exception crosses the C ABI)
-        }
-      }
+    for (int i = 0; i < 4; i++) {
+      if (serial_queue)
+        queue_lane(i);
+      else
+        worker[i]->submit([&queue_lane, i] { queue_lane(i); });
     }
     ZG_CRUMB("prove: qap_h rest");
     if (h_status == ZG_OK && !(hold >= 3)) h_status = qap_h(hold >= 1 && hold <= 3 ? hold : (head_first ? 1 : 0), 2);
@@ -503,12 +625,8 @@ struct ProvingKeyDev : PkBase {
     const MsmTable h_tab{H_len, 0, H_c, H_levels};
     if (h_status == ZG_OK) h_status = o1->msm_launch(ctx, H, (const uint32_t*)tmp, H_len, 1, h_c, H_levels ? &h_tab : nullptr);
     ZG_CRUMB("prove: joining lane threads");
-    for (int i = 0; i < 4; i++) {
-      if (workers[i].joinable())
-        workers[i].join();
-      else
-        queue_lane(i);
-    }
+    if (!serial_queue)
+      for (int i = 0; i < 4; i++) worker[i]->wait();
     // From here on kernels of this proof are queued on five streams; they read w, bsc and tmp and write the lanes' pinned
     // buffers.  Whatever fails below, every stream is drained before the error is returned, so that the next proof on
     // this key starts on idle lanes.
