@@ -81,11 +81,14 @@ def ntt_report(ctx, zeth_amd):
     as fractions of the HBM roofline (64 m algorithmic bytes per transform) and of the multiply peak."""
     import ctypes
 
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_ntt.json")))
-    except (OSError, ValueError):
-        pass
+    pmc, pmc_src = {}, None
+    for name in ("r3_pmc_ntt.json", "r2_pmc_ntt.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            pmc_src = "profiles/" + name
+            break
+        except (OSError, ValueError):
+            pass
     out = []
     for lg in (19, 22):
         m = 1 << lg
@@ -105,7 +108,7 @@ def ntt_report(ctx, zeth_amd):
         out.append({"log_m": lg, "kernels_ms": k_ms, "per_variant_ms": per,
                     "hbm": {"algorithmic_bytes": 64 * m, "GBps": 64 * m / (k_ms * 1e-3) / 1e9, "frac": 64 * m / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                     "mac": {"per_transform": (m // 2) * lg * 136, "frac": (m // 2) * lg * 136 / (k_ms * 1e-3) / PEAK_MAC_PER_S},
-                    "traffic": pmc.get(str(lg))})
+                    "traffic": dict(pmc[str(lg)], source=pmc_src + " (collected in separate rocprofv3 --pmc runs, not in this run)") if str(lg) in pmc else None})
     return {"curve": "alt-bn128 Fr", "transforms": out,
             "note": "the prover's three variants, mean of their medians; 64 m bytes = one read and one write of the vector "
             "(SURVEY 8d), (m/2) log2 m butterflies x 136 MAC; traffic = FETCH_SIZE/WRITE_SIZE per transform "
@@ -349,16 +352,16 @@ def main():
         hbm_bytes = n_local * digits * 68
         # HBM bytes per k_accum launch from the PMC passes of this same workload (the counters cannot be read from
         # inside this process); only quoted for the size they were collected at
-        traffic = None
-        try:
-            pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
-            if not os.path.exists(pmc_path):
-                pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
-            pmc = json.load(open(pmc_path))["kernels"]["k_accum"]
-            if n_local == 1 << 24 and pmc.get("digits_per_scalar", 16) == digits:
-                traffic = pmc["FETCH_SIZE_bytes_per_launch"] + pmc["WRITE_SIZE_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = traffic_source = None
+        for name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["k_accum"]
+                if n_local == 1 << 24 and pmc.get("digits_per_scalar", 16) == digits:
+                    traffic = pmc["FETCH_SIZE_bytes_per_launch"] + pmc["WRITE_SIZE_bytes_per_launch"]
+                    traffic_source = "profiles/" + name + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this workload; NOT measured in this run)"
+                break
+            except (OSError, KeyError, ValueError):
+                continue
         out = {
             "metric": "bn254_g1_msm_2^%d_throughput" % args.log_n,
             "value": n_total / (elapsed / args.steps),
@@ -388,7 +391,8 @@ def main():
                 "frac": achieved / PEAK_MAC_PER_S,
                 "kernel_ms": k_ms,
                 "traffic": traffic,
-                "traffic_unit": "bytes per k_accum launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; profiles/r*_pmc_hbm_traffic.json)",
+                "traffic_source": traffic_source,
+                "traffic_unit": "bytes per k_accum launch (FETCH_SIZE + WRITE_SIZE)",
                 "algorithmic_bytes": hbm_bytes,
                 "hbm_algorithmic_GBps": hbm_bytes / (k_ms * 1e-3) / 1e9,
                 "hbm_frac": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

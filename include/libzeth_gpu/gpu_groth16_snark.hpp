@@ -281,6 +281,23 @@ public:
         return prove(primary, auxiliary, random_field_element<ppT>(), random_field_element<ppT>());
     }
 
+    /// Creates every prover of every device now and runs one proof of the given assignment on each, so that no later
+    /// caller pays for a clone (its streams, scratch and page-locked staging: tens of milliseconds) or for a prover's
+    /// first proof.  Optional -- provers are otherwise created when first needed; a server calls it once before it
+    /// starts to serve.  Waits for proofs in flight to finish.
+    void warm_up(const r1cs_primary_input<Fr<ppT>> &primary, const r1cs_auxiliary_input<Fr<ppT>> &auxiliary)
+    {
+        std::lock_guard<std::mutex> one_at_a_time(warm_up_m_); // two of these at once would each hold half the provers
+        std::vector<std::unique_ptr<lease>> held;
+        for (size_t i = 0; i < devices_.size() * max_per_device_; i++) {
+            held.emplace_back(new lease(*this)); // this thread holds the others: every lease is a different prover
+        }
+        const Fr<ppT> r = random_field_element<ppT>(), s = random_field_element<ppT>();
+        for (auto &l : held) {
+            (void)l->prover().prove(primary, auxiliary, r, s);
+        }
+    }
+
 private:
     struct slot {
         std::unique_ptr<device_proving_key<ppT>> prover;
@@ -368,6 +385,7 @@ private:
     std::vector<std::unique_ptr<device_state>> devices_;
     const size_t max_per_device_;
     mutable std::mutex m_;
+    std::mutex warm_up_m_;
     std::condition_variable cv_;
     size_t in_flight_, peak_in_flight_, proofs_;
 };

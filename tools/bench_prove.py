@@ -25,8 +25,74 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="proofs kept in flight on the device for the throughput figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--pool-dir", default=None, help="with --through-pool: write the C++ driver's input files here and keep them")
+    ap.add_argument("--through-pool", action="store_true",
+                    help="also prove through the C++ host module: K caller threads on one device_proving_key_pool "
+                         "(build/host_adapter_test bench_pool), the proof compared byte for byte with this script's")
     args = ap.parse_args()
     print(json.dumps(measure(args)), flush=True)
+
+
+def r1cs_file_bytes(cs):
+    """The constraint system in Zeth's r1cs_write_bytes format (libzeth/serialization/r1cs_serialization.tcc:199-275):
+    u64 primary, u64 auxiliary, u64 constraints, then per constraint a, b, c as u32 term count + (u64 index, Fr big-endian)."""
+    import numpy as np
+
+    recs, rps = [], []
+    for k in range(3):
+        cols = np.asarray(cs.col[k], dtype=np.uint64)
+        rec = np.zeros((len(cols), 40), dtype=np.uint8)
+        rec[:, :8] = cols.view(np.uint8).reshape(-1, 8)
+        cache = {}
+        vals = cs.val[k]
+        be = bytearray(32 * len(vals))
+        for t, v in enumerate(vals):
+            b = cache.get(v)
+            if b is None:
+                b = cache[v] = int(v).to_bytes(32, "big")
+            be[32 * t:32 * t + 32] = b
+        rec[:, 8:] = np.frombuffer(bytes(be), dtype=np.uint8).reshape(-1, 32)
+        recs.append(rec)
+        rps.append(np.asarray(cs.row_ptr[k], dtype=np.int64).tolist())
+    parts = [np.array([cs.num_inputs, cs.num_variables - cs.num_inputs, cs.num_constraints], dtype=np.uint64).tobytes()]
+    for i in range(cs.num_constraints):
+        for k in range(3):
+            lo, hi = rps[k][i], rps[k][i + 1]
+            parts.append((hi - lo).to_bytes(4, "little"))
+            parts.append(recs[k][lo:hi].tobytes())
+    return b"".join(parts)
+
+
+def through_pool(args, cs, primary, aux):
+    """groth16 proofs through include/libzeth_gpu's device_proving_key_pool from K caller threads (the C++ boundary a
+    prover_server would bind): key from the same secrets by the C++ generator, (r, s) as above.  Runs BEFORE this process
+    touches the GPU: a second process with a live HIP context on the same device (idle, but holding its hardware queues)
+    halves the driver's throughput with four proofs in flight (228 against 440 proofs/s, measured)."""
+    import contextlib
+    import subprocess
+    import tempfile
+
+    driver = os.path.join(ROOT, "build", "host_adapter_test")
+    K = max(1, int(args.in_flight or 1))
+    keep = getattr(args, "pool_dir", None)  # keep the driver's input files there (to run it under a profiler afterwards)
+    with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as d:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "r1cs"), "wb") as f:
+            f.write(r1cs_file_bytes(cs))
+        full = list(primary) + list(aux)
+        with open(os.path.join(d, "asg"), "wb") as f:
+            f.write(len(full).to_bytes(8, "little") + b"".join(int(v).to_bytes(32, "big") for v in full))
+        p = subprocess.run([driver, "bench_pool", args.curve, os.path.join(d, "r1cs"), os.path.join(d, "asg"), str(len(primary)),
+                            str(K), str(max(4, args.steps)), str(K), os.path.join(d, "proof")], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ))
+        if p.returncode != 0:
+            raise SystemExit("bench_pool failed (%d): %s %s" % (p.returncode, p.stdout, p.stderr))
+        if p.stderr:
+            sys.stderr.write(p.stderr)
+        res = json.loads(p.stdout.strip().splitlines()[-1])
+        got = open(os.path.join(d, "proof"), "rb").read()
+    res["_proof_bytes"] = got
+    return res
 
 
 def cpu_prove(cid, cs, extra, primary, aux, rb, sb, threads):
@@ -77,6 +143,11 @@ def measure(args, ctx=None):
     t = time.time()
     cs, primary, aux = joinsplit_shaped(info.r, seed=1, scale=args.scale, constraints=getattr(args, "constraints", 0))
     t_circ = time.time() - t
+    pool_res = None
+    if getattr(args, "through_pool", False):
+        if ctx is not None:
+            raise SystemExit("--through-pool must run before this process creates its device context")
+        pool_res = through_pool(args, cs, primary, aux)
     if ctx is None:
         ctx = zeth_amd.Context(0)
     t = time.time()
@@ -182,6 +253,11 @@ def measure(args, ctx=None):
         mvk.alpha_g1, mvk.beta_g2, mvk.delta_g2, mvk.ABC_g1 = vk.alpha_g1, vk.beta_g2, vk.delta_g2, vk.ABC_g1
         res["verifies"] = bool(verify(C, mvk, primary, proof))
     dpk.free()
+    if pool_res is not None:
+        from zeth_model import BLS12_377, BN254, proof_to_bytes
+
+        pool_res["proof_equals_ctypes_path"] = pool_res.pop("_proof_bytes") == proof_to_bytes(BN254 if cid == 0 else BLS12_377, proof)
+        res["through_cpp_pool"] = pool_res
     return res
 
 

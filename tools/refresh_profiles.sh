@@ -1,7 +1,7 @@
 #!/bin/bash
 # profiles/ from the outputs of tools/final_measure.sh (gpurun_out/final): run here after the GPU calls
 O=gpurun_out/final
-R=r2
+R=r3
 cp $O/bench.json profiles/${R}_bench_msm2p24.json
 cp $O/bench_windowed.json profiles/${R}_bench_msm2p24_windowed.json
 python3 tools/prof_summary.py $O/prof_bench/bench_results.db 13 > profiles/${R}_bench_msm2p24_kernel_stats.txt

@@ -398,10 +398,12 @@ template<typename ppT> int cmd_bench_pool(char **argv)
         lat.push_back(std::chrono::duration<double, std::milli>(clock::now() - a).count());
     }
     std::sort(lat.begin(), lat.end());
+    t0 = clock::now();
+    pool.warm_up(primary, auxiliary); // every prover exists and has proved once before the clock starts
+    const double warm_up_s = std::chrono::duration<double>(clock::now() - t0).count();
     std::atomic<size_t> ready(0), bad(0);
     std::atomic<bool> go(false);
     auto worker = [&]() {
-        (void)pool.prove(primary, auxiliary, r, s); // creates this caller's prover before the clock starts
         ready++;
         while (!go.load()) {
             std::this_thread::yield();
@@ -434,7 +436,7 @@ template<typename ppT> int cmd_bench_pool(char **argv)
               << ", \"in_flight_per_device\": " << in_flight << ", \"peak_in_flight\": " << pool.peak_in_flight() << ", \"proofs\": "
               << n_threads * per_thread << ", \"wall_ms\": " << wall * 1e3 << ", \"proofs_per_s_per_gpu\": " << n_threads * per_thread / wall
               << ", \"ms_per_proof_median_one_caller\": " << lat[lat.size() / 2] << ", \"ms_per_proof_min_one_caller\": " << lat[0]
-              << ", \"keygen_s\": " << keygen_s << ", \"upload_and_first_proof_s\": " << upload_s << ", \"all_equal_to_serial_proof\": true}\n";
+              << ", \"keygen_s\": " << keygen_s << ", \"upload_and_first_proof_s\": " << upload_s << ", \"warm_up_s\": " << warm_up_s << ", \"all_equal_to_serial_proof\": true}\n";
     return 0;
 }
 
