@@ -9,9 +9,11 @@ import re
 import sys
 from collections import defaultdict
 
-rows = []
-for f in glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True):
-    rows += list(csv.DictReader(open(f)))
+import os
+
+# the newest run only: a directory that was profiled into twice holds two files whose dispatch ids collide
+files = sorted(glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
+rows = list(csv.DictReader(open(files[-1])))
 disp = {}
 for r in rows:
     d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})

@@ -334,7 +334,9 @@ struct ProvingKeyDev : PkBase {
     ZG_TRY(dev_copy(&B2, v->B_g2, v->B_len));
     if (plain && v->B_len) ZG_TRY(o2->to_mont(ctx, B2, v->B_len));
     {
-      static const int lane_table_c = zg_knob("ZG_PK_LANE_TABLE_C") ? atoi(zg_knob("ZG_PK_LANE_TABLE_C")) : 17;
+      static const int lane_table_c = zg_knob("ZG_PK_G2_TABLE_C")     ? atoi(zg_knob("ZG_PK_G2_TABLE_C"))
+                                      : zg_knob("ZG_PK_LANE_TABLE_C") ? atoi(zg_knob("ZG_PK_LANE_TABLE_C"))
+                                                                      : 17;
       if (lane_table_c) ZG_TRY(make_table(o2, (void**)&B2, v->B_len, sizeof(Affine<Fq2T>), lane_table_c, &B2_c, &B2_levels));
     }
     for (size_t i = 0; i < v->B_len; i++)
