@@ -51,6 +51,6 @@ elif [ "$1" = "3" ]; then
     timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d "$O/pmc_tcc" -- python3 "$R/bench.py" --no-cpu-baseline --no-prove --no-windowed --no-g2 --no-ntt --steps 3 --warmup 1 > "$O/pmc_tcc.log" 2>&1 &&
     echo part3 done
 else
-    echo "usage: $0 1|2" >&2
+    echo "usage: $0 1|2|3" >&2
     exit 2
 fi

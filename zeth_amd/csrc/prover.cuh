@@ -375,10 +375,10 @@ struct ProvingKeyDev : PkBase {
       // window instead of 1024 cut their reduction's instruction count 2.6x (profiles/r2_prove_valu_by_kernel.txt: the
       // reductions were 37 % of a proof's vector instructions), worth +10 % proofs/s with four proofs in flight.
       // (set per proof in prove_impl: lane_segments())
-    }  // the SAME priority as the main stream.  With the lanes one level below it (default or lowest priority, both tried,
-       // rounds 1 and 2) a proof does not complete within 90 s: no fault, the process stays killable, and with equal
-       // priorities the same queue of work takes 4 ms -- the lanes' queues are not served while the high-priority queue
-       // exists, even when it is idle.  Cause inside the runtime's queue scheduling not found; not pursued.
+    }  // the SAME priority as the main stream.  With mixed priorities and three or more lanes queued at once by their own
+       // threads a proof never completes (no fault, killable; every queue pending, none served).  Bisected in round 3
+       // (tools/diag_prio.py, profiles/r3_stream_priority_bisect.jsonl): not the cross-stream event, not
+       // reallocation, not scratch, not GPU_MAX_HW_QUEUES; a pure-HIP reproducer of the same shape never stalls.
     for (int i = 0; i < 4; i++) {
       worker[i] = new LaneWorker();
       if ((num_vars * sizeof(Fr)) >= PAR_UPLOAD_MIN) {
