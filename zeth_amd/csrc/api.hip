@@ -85,7 +85,10 @@ int zg_ctx_create(int device, zg_ctx** out) {
 
 }  // extern "C"
 
-// prio > 0: highest stream priority, prio == 0: the default priority, prio < 0: lowest
+// prio > 0: highest stream priority, prio == 0: the default priority, prio < 0: lowest.  Internal: every caller in the
+// shipped library passes +1.  Contexts of DIFFERENT priorities whose streams are fed by several threads at once stall the
+// runtime's queues (profiles/r3_stream_priority_bisect.jsonl); the other values exist for the debug build's
+// knobs (tools/diag_prio.py), which is how that was bisected.
 int zg_ctx_create_prio(int device, int prio, zg_ctx** out) {
   if (!out) return ZG_ERR_INVALID_ARGUMENT;
   *out = nullptr;
