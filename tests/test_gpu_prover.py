@@ -249,6 +249,48 @@ def test_failed_prove_is_followed_by_a_correct_proof():
     assert p.returncode == 0 and "failed-prove ok" in p.stdout, p.stdout + p.stderr
 
 
+def _staged_upload_body():
+    """Runs in a process of its own against the -DZG_DEBUG_KNOBS build with ZG_PAR_UPLOAD_MIN_KB=1 and ZG_PAR_STAGE_KB=1: the
+    assignment then takes the staged four-thread upload that the shipped library uses from 32 MB on (1 KB staging halves:
+    several chunks per lane, both halves reused; ragged and nearly empty quarters)."""
+    import zeth_amd
+
+    ctx = zeth_amd.Context(0)
+    for cid, C, ni, na, nc in ((0, BN254, 2, 900, 1500), (1, BLS12_377, 3, 37, 64), (0, BN254, 1, 1031, 700)):
+        rng = random.Random(1000 + na)
+        cs, primary, aux = random_r1cs(C, rng, ni, na, nc)
+        pk, _ = generator_from_secrets_fast(C, cs, rng)
+        dpk = zeth_amd.ProvingKey.from_model(ctx, cid, pk, C.r)
+        snark = zeth_amd.Groth16Snark(ctx, cid)
+        want = cpu_oracle.prove(cid, C, pk, primary, aux, 5, 7, chunks=2)
+        for _ in range(2):
+            assert snark.generate_proof(dpk, primary, aux, 5, 7) == want
+        twin = dpk.clone()
+        assert snark.generate_proof(twin, primary, aux, 5, 7) == want
+        twin.free()
+        dpk.free()
+    ctx.close()
+    print("staged-upload ok")
+
+
+def test_staged_parallel_upload_gives_the_same_proof():
+    """The upload path of large assignments (four lane threads through page-locked staging, prover.cuh upload_slice), forced
+    at test sizes through the debug build's knobs; at full size it is checked by tools/bench_prove.py (BLS12-377, 2^22
+    constraints: bit_exact_vs_cpu_oracle in profiles/r3_prove_bls377_2p22.json)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "build", "dbg", "libzeth_gpu.so")
+    assert os.path.exists(dbg), "build/dbg/libzeth_gpu.so is missing: run `make dbg`"
+    code = "import sys; sys.path[:0] = [%r, %r, %r]; import test_gpu_prover as T; T._staged_upload_body()" % (
+        root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
+    env = dict(os.environ, ZETH_GPU_LIBRARY=dbg, ZG_PAR_UPLOAD_MIN_KB="1", ZG_PAR_STAGE_KB="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110, env=env)
+    assert p.returncode == 0 and "staged-upload ok" in p.stdout, p.stdout + p.stderr
+
+
 def test_shipped_library_ignores_the_fault_injection_knob(ctx, monkeypatch):
     import zeth_amd
 

@@ -197,6 +197,10 @@ struct ProvingKeyDev : PkBase {
   LaneWorker* worker[4] = {nullptr, nullptr, nullptr, nullptr};
   // page-locked staging of the parallel upload: two halves per lane, and the events that say a half's copy has left it
   static constexpr size_t STAGE_BYTES = (size_t)2 << 20;
+  // (debug builds: ZG_PAR_UPLOAD_MIN_KB / ZG_PAR_STAGE_KB shrink the threshold and the staging halves, so that a test-sized
+  // proof runs the staged upload with several chunks per lane -- tests/test_gpu_prover.py)
+  size_t stage_bytes = zg_knob("ZG_PAR_STAGE_KB") ? (size_t)atoi(zg_knob("ZG_PAR_STAGE_KB")) << 10 : STAGE_BYTES;
+  size_t par_upload_min = zg_knob("ZG_PAR_UPLOAD_MIN_KB") ? (size_t)atoi(zg_knob("ZG_PAR_UPLOAD_MIN_KB")) << 10 : PAR_UPLOAD_MIN;
   char* stage[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t stage_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   uint32_t dense_hint[4] = {0, 0, 0, 0};
@@ -381,8 +385,8 @@ struct ProvingKeyDev : PkBase {
        // reallocation, not scratch, not GPU_MAX_HW_QUEUES; a pure-HIP reproducer of the same shape never stalls.
     for (int i = 0; i < 4; i++) {
       worker[i] = new LaneWorker();
-      if ((num_vars * sizeof(Fr)) >= PAR_UPLOAD_MIN) {
-        ZG_HIP(hipHostMalloc((void**)&stage[i], 2 * STAGE_BYTES, hipHostMallocDefault));
+      if ((num_vars * sizeof(Fr)) >= par_upload_min) {
+        ZG_HIP(hipHostMalloc((void**)&stage[i], 2 * stage_bytes, hipHostMallocDefault));
         for (auto& e : stage_ev[i]) ZG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       }
     }
@@ -448,12 +452,12 @@ struct ProvingKeyDev : PkBase {
     if (hipSetDevice(ctx->device) != hipSuccess) return ZG_ERR_HIP;
     hipStream_t ls = lane[i]->stream;
     size_t k = 0;
-    for (size_t off = 0; off < bytes; off += STAGE_BYTES, k++) {
-      const size_t len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+    for (size_t off = 0; off < bytes; off += stage_bytes, k++) {
+      const size_t len = bytes - off < stage_bytes ? bytes - off : stage_bytes;
       const int h = (int)(k & 1);
       if (k >= 2) ZG_HIP(hipEventSynchronize(stage_ev[i][h]));
-      memcpy(stage[i] + h * STAGE_BYTES, src + off, len);
-      ZG_HIP(hipMemcpyAsync(dst + off, stage[i] + h * STAGE_BYTES, len, hipMemcpyHostToDevice, ls));
+      memcpy(stage[i] + h * stage_bytes, src + off, len);
+      ZG_HIP(hipMemcpyAsync(dst + off, stage[i] + h * stage_bytes, len, hipMemcpyHostToDevice, ls));
       ZG_HIP(hipEventRecord(stage_ev[i][h], ls));
     }
     ZG_HIP(hipStreamSynchronize(ls));
@@ -467,7 +471,7 @@ struct ProvingKeyDev : PkBase {
     if (n_primary) ZG_HIP(hipMemcpyAsync(assign, primary, n_primary * sizeof(Fr), hipMemcpyHostToDevice, st));
     const size_t aux_bytes = n_aux * sizeof(Fr);
     static const bool no_par_upload = zg_knob("ZG_PROVE_NO_PAR_UPLOAD") != nullptr;  // measurement knob
-    if (aux_bytes >= PAR_UPLOAD_MIN && stage[0] && !no_par_upload) {
+    if (aux_bytes >= par_upload_min && stage[0] && !no_par_upload) {
       int status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
       const size_t per = ((aux_bytes / 4) + 255) & ~(size_t)255;
       for (int i = 0; i < 4; i++) {
