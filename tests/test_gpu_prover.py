@@ -256,7 +256,9 @@ def _staged_upload_body():
     import zeth_amd
 
     ctx = zeth_amd.Context(0)
-    for cid, C, ni, na, nc in ((0, BN254, 2, 900, 1500), (1, BLS12_377, 3, 37, 64), (0, BN254, 1, 1031, 700)):
+    # (the last case is large enough for the early half-range evaluations of the A and L queries: >= 8192 auxiliary
+    # variables and, with ZG_PK_TABLE_MIN lowered, tables for both)
+    for cid, C, ni, na, nc in ((0, BN254, 2, 900, 1500), (1, BLS12_377, 3, 37, 64), (0, BN254, 1, 1031, 700), (0, BN254, 2, 9001, 5000)):
         rng = random.Random(1000 + na)
         cs, primary, aux = random_r1cs(C, rng, ni, na, nc)
         pk, _ = generator_from_secrets_fast(C, cs, rng)
@@ -286,7 +288,7 @@ def test_staged_parallel_upload_gives_the_same_proof():
     assert os.path.exists(dbg), "build/dbg/libzeth_gpu.so is missing: run `make dbg`"
     code = "import sys; sys.path[:0] = [%r, %r, %r]; import test_gpu_prover as T; T._staged_upload_body()" % (
         root, os.path.join(root, "oracle"), os.path.join(root, "tests"))
-    env = dict(os.environ, ZETH_GPU_LIBRARY=dbg, ZG_PAR_UPLOAD_MIN_KB="1", ZG_PAR_STAGE_KB="1")
+    env = dict(os.environ, ZETH_GPU_LIBRARY=dbg, ZG_PAR_UPLOAD_MIN_KB="1", ZG_PAR_STAGE_KB="1", ZG_PK_TABLE_MIN="1023")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110, env=env)
     assert p.returncode == 0 and "staged-upload ok" in p.stdout, p.stdout + p.stderr
 

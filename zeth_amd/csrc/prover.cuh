@@ -104,9 +104,9 @@ struct CsrDev {
 template <class Fr>
 __global__ void __launch_bounds__(256) k_build_w(const Fr* __restrict__ primary, size_t n_primary,
                                                   const Fr* __restrict__ aux, size_t n_aux, int plain,
-                                                  Fr* __restrict__ w_full) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n_primary + n_aux) return;
+                                                  Fr* __restrict__ w_full, size_t lo, size_t hi) {  // entries [lo, hi) of 1 || w
+  size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi || i > n_primary + n_aux) return;
   Fr x;
   if (i == 0) {
     x = Fr::one();
@@ -193,8 +193,12 @@ struct ProvingKeyDev : PkBase {
   // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
   Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
   Fr z_inv;
-  zg_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
-  LaneWorker* worker[4] = {nullptr, nullptr, nullptr, nullptr};
+  // lanes 0-3: the B (G2), A, L and B (G1) evaluations; lanes 4, 5 (large proofs only, `early`): the A and L evaluations
+  // over the first half of the assignment, started while the second half is still crossing PCIe
+  zg_ctx* lane[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  LaneWorker* worker[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool early = false;
+  hipEvent_t w_half = nullptr;
   // page-locked staging of the parallel upload: two halves per lane, and the events that say a half's copy has left it
   static constexpr size_t STAGE_BYTES = (size_t)2 << 20;
   // (debug builds: ZG_PAR_UPLOAD_MIN_KB / ZG_PAR_STAGE_KB shrink the threshold and the staging halves, so that a test-sized
@@ -219,6 +223,7 @@ struct ProvingKeyDev : PkBase {
     for (auto& l : lane)
       if (l) zg_ctx_destroy(l);
     if (w_ready) hipEventDestroy(w_ready);
+    if (w_half) hipEventDestroy(w_half);
     if (owns_key) {
       for (auto& M : mat) {
         hipFree(M.row_ptr);
@@ -370,7 +375,14 @@ struct ProvingKeyDev : PkBase {
     // (debug builds: ZG_LANE_PRIO = 1 | 0 | -1 puts the lanes at the highest / default / lowest stream priority and
     // ZG_LANE_PROFILE turns their phase marks on, for tools/diag_prio.py)
     static const int lane_prio = zg_knob("ZG_LANE_PRIO") ? atoi(zg_knob("ZG_LANE_PRIO")) : +1;
-    for (auto& l : lane) {
+    // A proof whose assignment takes the staged upload (>= 32 MB) and whose A and L queries have tables evaluates the
+    // first half of both while the second half is uploaded: BLS12-377, 2^22 constraints, 168 MB -- the device no longer
+    // sits idle for the second 1.6 ms of the upload (debug builds: ZG_PROVE_NO_EARLY turns it off)
+    early = (num_vars * sizeof(Fr)) >= par_upload_min && A_levels > 0 && L_levels > 0 && num_vars - num_inputs >= 8192 &&
+            !zg_knob("ZG_PROVE_NO_EARLY");
+    const int n_lanes = early ? 6 : 4;
+    for (int li = 0; li < n_lanes; li++) {
+      zg_ctx*& l = lane[li];
       ZG_TRY(zg_ctx_create_prio(ctx->device, lane_prio, &l));
       l->want_dense = true;
       l->profiling = zg_knob("ZG_LANE_PROFILE") != nullptr;
@@ -383,6 +395,8 @@ struct ProvingKeyDev : PkBase {
        // threads a proof never completes (no fault, killable; every queue pending, none served).  Bisected in round 3
        // (tools/diag_prio.py, profiles/r3_stream_priority_bisect.jsonl): not the cross-stream event, not
        // reallocation, not scratch, not GPU_MAX_HW_QUEUES; a pure-HIP reproducer of the same shape never stalls.
+    for (int i = 4; i < n_lanes; i++) worker[i] = new LaneWorker();
+    ZG_HIP(hipEventCreateWithFlags(&w_half, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
       worker[i] = new LaneWorker();
       if ((num_vars * sizeof(Fr)) >= par_upload_min) {
@@ -464,29 +478,55 @@ struct ProvingKeyDev : PkBase {
     return ZG_OK;
   }
 
-  // 1 || w in Montgomery form on the device
-  int load_assignment(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form) {
+  // 1 || w in Montgomery form on the device.  `on_half` (may be empty; used when `early` is set and the upload is staged):
+  // called with h once aux[0, h) is on the device and entries [0, 1 + n_primary + h) of 1 || w are queued on the main
+  // stream with `w_half` recorded behind them -- the rest of aux is uploaded after it returns.
+  int load_assignment(const void* primary, size_t n_primary, const void* aux, size_t n_aux, int form,
+                      const std::function<int(size_t)>& on_half = nullptr) {
     if (n_primary != num_inputs || n_primary + n_aux != num_vars) return ZG_ERR_INVALID_ARGUMENT;
     hipStream_t st = ctx->stream;
     if (n_primary) ZG_HIP(hipMemcpyAsync(assign, primary, n_primary * sizeof(Fr), hipMemcpyHostToDevice, st));
     const size_t aux_bytes = n_aux * sizeof(Fr);
+    const int plain = form == ZG_FORM_PLAIN;
+    auto build_w = [&](size_t lo, size_t hi) {  // entries [lo, hi) of 1 || w
+      if (hi > lo)
+        hipLaunchKernelGGL((k_build_w<Fr>), dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, assign, n_primary,
+                           assign + n_primary, n_aux, plain, w, lo, hi);
+    };
     static const bool no_par_upload = zg_knob("ZG_PROVE_NO_PAR_UPLOAD") != nullptr;  // measurement knob
     if (aux_bytes >= par_upload_min && stage[0] && !no_par_upload) {
-      int status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
-      const size_t per = ((aux_bytes / 4) + 255) & ~(size_t)255;
-      for (int i = 0; i < 4; i++) {
-        const size_t lo = per * i < aux_bytes ? per * i : aux_bytes, hi = lo + per < aux_bytes ? lo + per : aux_bytes;
-        char* dst = reinterpret_cast<char*>(assign + n_primary) + lo;
-        const char* src = static_cast<const char*>(aux) + lo;
-        worker[i]->submit([this, i, dst, src, lo, hi, &status] { status[i] = upload_slice(i, dst, src, hi - lo); });
+      auto upload_range = [&](size_t b0, size_t b1) -> int {  // bytes [b0, b1) of aux, a quarter per lane thread
+        int status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
+        const size_t bytes = b1 - b0;
+        const size_t per = ((bytes / 4) + 255) & ~(size_t)255;
+        for (int i = 0; i < 4; i++) {
+          const size_t lo = per * i < bytes ? per * i : bytes, hi = lo + per < bytes ? lo + per : bytes;
+          char* dst = reinterpret_cast<char*>(assign + n_primary) + b0 + lo;
+          const char* src = static_cast<const char*>(aux) + b0 + lo;
+          worker[i]->submit([this, i, dst, src, lo, hi, &status] { status[i] = upload_slice(i, dst, src, hi - lo); });
+        }
+        for (int i = 0; i < 4; i++) worker[i]->wait();
+        for (int i = 0; i < 4; i++) ZG_TRY(status[i]);
+        return ZG_OK;
+      };
+      // (debug builds: ZG_PROVE_EARLY_PCT = the first part's share of the assignment, in percent)
+      static const size_t early_pct = zg_knob("ZG_PROVE_EARLY_PCT") ? (size_t)atoi(zg_knob("ZG_PROVE_EARLY_PCT")) : 50;
+      const size_t half = (early && on_half) ? n_aux * early_pct / 100 : 0;
+      if (half) {
+        ZG_TRY(upload_range(0, half * sizeof(Fr)));
+        build_w(0, 1 + n_primary + half);
+        ZG_HIP(hipEventRecord(w_half, st));
+        ZG_TRY(on_half(half));
+        ZG_TRY(upload_range(half * sizeof(Fr), aux_bytes));
+        build_w(1 + n_primary + half, num_vars + 1);
+      } else {
+        ZG_TRY(upload_range(0, aux_bytes));
+        build_w(0, num_vars + 1);
       }
-      for (int i = 0; i < 4; i++) worker[i]->wait();
-      for (int i = 0; i < 4; i++) ZG_TRY(status[i]);
-    } else if (n_aux) {
-      ZG_HIP(hipMemcpyAsync(assign + n_primary, aux, aux_bytes, hipMemcpyHostToDevice, st));
+    } else {
+      if (n_aux) ZG_HIP(hipMemcpyAsync(assign + n_primary, aux, aux_bytes, hipMemcpyHostToDevice, st));
+      build_w(0, num_vars + 1);
     }
-    hipLaunchKernelGGL((k_build_w<Fr>), dim3((unsigned)((num_vars + 1 + 255) / 256)), dim3(256), 0, st, assign, n_primary,
-                       assign + n_primary, n_aux, form == ZG_FORM_PLAIN, w);
     return ZG_OK;
   }
 
@@ -534,7 +574,49 @@ struct ProvingKeyDev : PkBase {
     };
     ZG_CRUMB_SLOT(4);
     ZG_CRUMB("prove: load_assignment");
-    ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
+    const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
+    const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
+    // Large proofs (`early`): the A and L evaluations are split at the middle of the assignment.  The first halves are
+    // queued on lanes 4 and 5 as soon as the first half of the assignment is on the device, by their own threads, while
+    // this thread goes on to upload the second half; lanes 1 and 2 then take the second halves (MsmTable::first).
+    size_t a_split = 0, l_split = 0;  // bases [0, split) go to the early lanes
+    int early_status[2] = {ZG_OK, ZG_OK};
+    struct JoinEarly {  // the early lanes' threads use this frame: they are joined on every way out, and after an error
+      ProvingKeyDev* pk;  // their streams are drained like the others' (Drain below)
+      bool armed = true;
+      ~JoinEarly() {
+        for (int i = 4; i < 6; i++) {
+          if (pk->worker[i]) pk->worker[i]->wait();
+          if (armed && pk->lane[i]) hipStreamSynchronize(pk->lane[i]->stream);
+        }
+      }
+    } join_early{this};
+    auto on_half = [&](size_t h) -> int {
+      a_split = 1 + n_primary + h;
+      l_split = h;
+      for (int i = 4; i < 6; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_half, 0));
+      worker[4]->submit([this, o1, a_split, &early_status] {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+          early_status[0] = ZG_ERR_HIP;
+          return;
+        }
+        const MsmTable t{A_len, 0, A_c, A_levels};
+        early_status[0] = o1->msm_launch(lane[4], A, (const uint32_t*)w, a_split, 1, 0, &t);
+      });
+      worker[5]->submit([this, o1, l_split, &early_status] {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+          early_status[1] = ZG_ERR_HIP;
+          return;
+        }
+        const MsmTable t{L_len, 0, L_c, L_levels};
+        early_status[1] = o1->msm_launch(lane[5], L, (const uint32_t*)(w + num_inputs + 1), l_split, 1, 0, &t);
+      });
+      return ZG_OK;
+    };
+    if (early)
+      ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form, on_half));
+    else
+      ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
     stamp("assignment queued");
     hipStream_t st = ctx->stream;
     if (B_len) hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
@@ -553,8 +635,6 @@ struct ProvingKeyDev : PkBase {
     } else {
       for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
     }
-    const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
-    const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
     XYZZ<Fq> At, Bt1, Ht, Lt;
     XYZZ<Fq2T> Bt2;
     // scalars are Montgomery residues in device memory
@@ -603,13 +683,13 @@ struct ProvingKeyDev : PkBase {
         return;
       }
       // (a query that has a table is evaluated over it: the window width is the table's, and the hint plays no part)
-      const MsmTable tabs[4] = {{B_len, 0, B2_c, B2_levels}, {A_len, 0, A_c, A_levels}, {L_len, 0, L_c, L_levels}, {B_len, 0, B1_c, B1_levels}};
+      const MsmTable tabs[4] = {{B_len, 0, B2_c, B2_levels}, {A_len, a_split, A_c, A_levels}, {L_len, l_split, L_c, L_levels}, {B_len, 0, B1_c, B1_levels}};
       const MsmTable* tab = tabs[i].D ? &tabs[i] : nullptr;
       const int c = tab ? 0 : width(dense_hint[i]);
       switch (i) {
         case 0: lane_status[0] = o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, c, tab); break;
-        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)w, A_len, 1, c, tab); break;
-        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1), L_len, 1, c, tab); break;
+        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)(w + a_split), A_len - a_split, 1, c, tab); break;
+        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1 + l_split), L_len - l_split, 1, c, tab); break;
         default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, c, tab); break;
       }
     };
@@ -633,6 +713,8 @@ struct ProvingKeyDev : PkBase {
     ZG_CRUMB("prove: joining lane threads");
     if (!serial_queue)
       for (int i = 0; i < 4; i++) worker[i]->wait();
+    for (int i = 4; i < 6; i++)
+      if (worker[i]) worker[i]->wait();
     // From here on kernels of this proof are queued on five streams; they read w, bsc and tmp and write the lanes' pinned
     // buffers.  Whatever fails below, every stream is drained before the error is returned, so that the next proof on
     // this key starts on idle lanes.
@@ -653,6 +735,7 @@ struct ProvingKeyDev : PkBase {
     }
     ZG_TRY(h_status);
     for (int i = 0; i < 4; i++) ZG_TRY(lane_status[i]);
+    for (int i = 0; i < 2; i++) ZG_TRY(early_status[i]);
     stamp("all work queued");
     // Host tail, ordered so that everything that does not need a device result runs while the GPU is busy:
     // the four blinding multiples of delta first, then each evaluation as its lane completes.
@@ -668,6 +751,11 @@ struct ProvingKeyDev : PkBase {
     const XYZZ<Fq2T> s_delta2 = xyzz_mul_limbs(X2(delta_g2), s_plain, Fr::N);
     stamp("delta multiples (host)");
     ZG_TRY(o1->msm_finish(lane[1], ZG_FORM_XYZZ_INTERNAL, &At));
+    if (a_split) {
+      XYZZ<Fq> lo;
+      ZG_TRY(o1->msm_finish(lane[4], ZG_FORM_XYZZ_INTERNAL, &lo));
+      xyzz_add(At, lo);
+    }
     stamp("A finished");
     XYZZ<Fq> gA = X1(alpha_g1);
     xyzz_add(gA, At);
@@ -687,6 +775,11 @@ struct ProvingKeyDev : PkBase {
     xyzz_add(gB, Bt2);
     xyzz_add(gB, s_delta2);
     ZG_TRY(o1->msm_finish(lane[2], ZG_FORM_XYZZ_INTERNAL, &Lt));
+    if (l_split) {
+      XYZZ<Fq> lo;
+      ZG_TRY(o1->msm_finish(lane[5], ZG_FORM_XYZZ_INTERNAL, &lo));
+      xyzz_add(Lt, lo);
+    }
     stamp("L finished");
     ZG_TRY(o1->msm_finish(ctx, ZG_FORM_XYZZ_INTERNAL, &Ht));
     for (int i = 0; i < 4; i++) dense_hint[i] = lane[i]->job_n ? lane[i]->job_dense + 1 : 0;
@@ -712,6 +805,7 @@ struct ProvingKeyDev : PkBase {
     memcpy(proof_out, &proof, sizeof(proof));
     stamp("proof normalised");
     drain.armed = false;  // every msm_finish above has synchronised its stream
+    join_early.armed = false;
     return ZG_OK;
   }
 
