@@ -79,6 +79,8 @@ struct zg_ctx {
   // not on its critical path (the prover's side lanes) asks for fewer: each segment's lane then pays the c-bit weighting
   // once for more buckets -- less work for the device, a longer dependent chain for this evaluation.
   uint32_t reduce_segments = 0;
+  uint32_t table_unit_len = 0;  // table mode: entries per work unit (0: the plan's own length, sized for dense scalars)
+  uint32_t table_segments = 0;  // table mode: at most this many bucket segments per group (0: the plan's own count)
   uint32_t job_dense = 0;  // scalars other than 0/1 seen by the last MSM on this context
   int pinned_reserve(size_t bytes) {
     if (bytes <= pinned_cap) return ZG_OK;

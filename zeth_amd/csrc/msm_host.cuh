@@ -184,6 +184,14 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     plan.T = ctx->reduce_segments;
     plan.k = plan.nb / plan.T;
   }
+  if (tab && ctx->table_unit_len && ctx->table_unit_len < plan.L) {
+    plan.L = ctx->table_unit_len;
+    plan.cap = plan.nb + (uint32_t)(plan.E / plan.L) + 1;
+  }
+  if (tab && ctx->table_segments && ctx->table_segments < plan.T) {  // table mode: the bit-sum tree's work goes with the segment count
+    plan.T = ctx->table_segments;
+    plan.k = plan.nb / plan.T;
+  }
   const MsmPlan& p = plan;
   ctx->job_W = p.W;
   ctx->job_c = p.c;

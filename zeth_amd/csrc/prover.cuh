@@ -667,6 +667,10 @@ struct ProvingKeyDev : PkBase {
       const int t = i == 0 ? lane_t_g2 : lane_t;  // lane 0 runs the G2 evaluation, whose additions cost 3x
       const bool small = dense_hint[i] < (1u << 16);
       lane[i]->reduce_segments = (small && t > 0 && (t & (t - 1)) == 0) ? (uint32_t)t : 0u;
+      static const int lane_ul = zg_knob("ZG_PROVE_LANE_UNIT_LEN") ? atoi(zg_knob("ZG_PROVE_LANE_UNIT_LEN")) : 0;  // tuning knob
+      lane[i]->table_unit_len = lane_ul > 0 ? (uint32_t)lane_ul : 0u;
+      static const int lane_tt = zg_knob("ZG_PROVE_LANE_TABLE_SEGMENTS") ? atoi(zg_knob("ZG_PROVE_LANE_TABLE_SEGMENTS")) : 0;  // tuning knob
+      lane[i]->table_segments = (lane_tt > 0 && (lane_tt & (lane_tt - 1)) == 0) ? (uint32_t)lane_tt : 0u;
     }
     int lane_status[4] = {ZG_OK, ZG_OK, ZG_OK, ZG_OK};
     // (debug builds: ZG_LANE_MASK, bit i clear = lane i's evaluation is skipped -- wrong proofs, for tools/diag_prio.py)
