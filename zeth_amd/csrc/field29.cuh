@@ -604,6 +604,140 @@ ZG_HD auto unpack_raw(const Fp<P>& s) {
   return unpack_shifted<0>(s);
 }
 
+// ---- product by a CONSTANT through its precomputed quotient ---------------------------------------------------------
+// For a constant w in [0, p) the table holds w itself (plain integer) and wq = floor(w 2^(B (NL+1)) / p).  Then
+//   q = floor(a wq / 2^(B (NL+1)))   -- the upper triangle of the limb product a x wq and two guard columns
+//   r = a w - q p                    -- exact, 0 <= r < 3 p, so the low NL limbs of a w + q (2^(B NL) - p) are r itself
+// 6 NL^2 / 4 + 3 NL limb products (144 for NL = 9) against the 2 NL^2 + NL (171) of the Montgomery product, no m_k = acc * inv
+// step, and the three triangles are independent up to q.  The value's form is whatever a's is (a x R' stays x w R'): the
+// transforms' butterflies multiply by twiddles only, which is what this is for (ntt.cuh).  q is at most two below the
+// true quotient: one from wq's floor and a / 2^(B (NL+1)) < 1, one from the dropped columns, whose total is below
+// NL LA 2^B / 2^B of a unit of column NL-1 -- far below the 2^(2B) that would reach q.
+template <class P>
+struct Shoup29 {
+  uint32_t w[K29<P>::NL];      // the constant: plain integer in [0, p), normalised limbs
+  uint32_t q[K29<P>::NL + 1];  // floor(w 2^(B (NL + 1)) / p), normalised limbs
+};
+
+// The table entry of the constant whose PLAIN value (not the Montgomery form) is wp: bit-serial division, for building
+// tables (one lane per entry on the device, or on the host)
+template <class P>
+ZG_HD Shoup29<P> shoup_from_plain(const Fp<P>& wp) {
+  using K = K29<P>;
+  constexpr int N = P::N;
+  static_assert((P::P[N - 1] >> 31) == 0, "2 rem must fit the words");
+  Shoup29<P> s;
+  const auto wl = unpack_raw(wp);
+#pragma unroll
+  for (int i = 0; i < K::NL; i++) s.w[i] = wl.v[i];
+  for (int i = 0; i <= K::NL; i++) s.q[i] = 0;
+  uint32_t rem[N];
+  for (int i = 0; i < N; i++) rem[i] = wp.v[i];
+  for (int bit = K::B * (K::NL + 1) - 1; bit >= 0; bit--) {
+    uint32_t cy = 0;
+    for (int i = 0; i < N; i++) {  // rem = 2 rem
+      const uint32_t t = (rem[i] << 1) | cy;
+      cy = rem[i] >> 31;
+      rem[i] = t;
+    }
+    uint32_t d[N];
+    uint32_t br = 0;
+    for (int i = 0; i < N; i++) {  // d = rem - p
+      const uint64_t x = (uint64_t)rem[i] - P::P[i] - br;
+      d[i] = (uint32_t)x;
+      br = (uint32_t)(x >> 63);
+    }
+    if (!br) {
+      for (int i = 0; i < N; i++) rem[i] = d[i];
+      s.q[bit / K::B] |= 1u << (bit % K::B);
+    }
+  }
+  return s;
+}
+
+// acc += sum over i in [I0, HI] of x[i] * y[K - i], the arrays of different lengths
+template <int I0, int HI, int K, int NX, int NY>
+ZG_HD void mac_column_xy(uint64_t& acc, const uint32_t (&x)[NX], const uint32_t (&y)[NY]) {
+  constexpr int n = HI - I0 + 1;
+  if constexpr (n >= 4) {
+    mac4(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1], x[I0 + 2], y[K - I0 - 2], x[I0 + 3], y[K - I0 - 3]);
+    mac_column_xy<I0 + 4, HI, K, NX, NY>(acc, x, y);
+  } else if constexpr (n == 3) {
+    mac2(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1]);
+    mac(acc, x[I0 + 2], y[K - I0 - 2]);
+  } else if constexpr (n == 2) {
+    mac2(acc, x[I0], y[K - I0], x[I0 + 1], y[K - I0 - 1]);
+  } else if constexpr (n == 1) {
+    mac(acc, x[I0], y[K - I0]);
+  }
+}
+
+template <class P>
+struct ShoupConsts {
+  using K = K29<P>;
+  // 2^(B NL) - p as normalised limbs
+  static constexpr typename K::Limbs neg_p() {
+    typename K::Limbs r{};
+    uint32_t cy = 1;
+    for (int i = 0; i < K::NL; i++) {
+      const uint32_t t = ((~K::PL.v[i]) & K::MASK) + cy;
+      r.v[i] = t & K::MASK;
+      cy = t >> K::B;
+    }
+    return r;
+  }
+  static constexpr typename K::Limbs NP = neg_p();
+};
+template <class P>
+constexpr typename K29<P>::Limbs ShoupConsts<P>::NP;
+
+// columns NL-1 .. 2 NL-1 of a x wq: the quotient's limbs
+template <class P, int K_, class A>
+ZG_HD void shoup_q_columns_from(uint64_t& acc, const A& a, const Shoup29<P>& c, uint32_t (&q)[K29<P>::NL]) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  // a_i wq_(k-i): i <= NL-1, k - i <= NL
+  constexpr int lo = K_ - NL > 0 ? K_ - NL : 0;
+  mac_column_xy<lo, NL - 1, K_, NL, NL + 1>(acc, a.v, c.q);
+  if constexpr (K_ >= NL + 1) q[K_ - NL - 1] = (uint32_t)acc & K::MASK;
+  acc >>= B;
+  if constexpr (K_ + 1 <= 2 * NL - 1) shoup_q_columns_from<P, K_ + 1>(acc, a, c, q);
+}
+// columns 0 .. NL-1 of a x w + q x (2^(B NL) - p)
+template <class P, int K_, class A>
+ZG_HD void shoup_r_columns_from(uint64_t& acc, const A& a, const Shoup29<P>& c, const uint32_t (&q)[K29<P>::NL],
+                                E29<P, 3, K29<P>::LNORM>& r) {
+  using K = K29<P>;
+  constexpr int NL = K::NL, B = K::B;
+  mac_column_xy<0, K_, K_, NL, NL>(acc, a.v, c.w);
+  mac_column_const<0, K_, K_, NL>(acc, q, ShoupConsts<P>::NP.v);
+  r.v[K_] = (uint32_t)acc & K::MASK;
+  acc >>= B;
+  if constexpr (K_ + 1 < NL) shoup_r_columns_from<P, K_ + 1>(acc, a, c, q, r);
+}
+template <class P, uint64_t VA, uint64_t LA>
+ZG_HD E29<P, 3, K29<P>::LNORM> mul_shoup(const E29<P, VA, LA>& a, const Shoup29<P>& c) {
+  using K = K29<P>;
+  constexpr int NL = K::NL;
+  constexpr uint64_t t = K::top_of_p() + 1;
+  constexpr unsigned __int128 ea = LA > VA * t ? LA : VA * t;  // a's limbs, the top one bounded by the value
+  constexpr unsigned __int128 qt = VA * t;                      // the quotient's top limb: q <= a w / p < a
+  static_assert(VA < (1ull << K::B), "mul_shoup: a must be below 2^(B (NL+1))");
+  static_assert(qt < ((unsigned __int128)1 << 32), "mul_shoup: the quotient's top limb overflows");
+  static_assert((unsigned __int128)NL * ea * K::LNORM + (unsigned __int128)(NL - 1) * K::LNORM * K::LNORM + qt * K::LNORM +
+                        ((unsigned __int128)1 << (64 - K::B)) < ((unsigned __int128)1 << 64),
+                "mul_shoup: a column overflows 64 bits -- carry() the operand first");
+  static_assert(3 * t <= (1ull << K::B), "mul_shoup: 3 p must fit NL limbs");
+  uint32_t q[NL];
+  uint64_t acc = 0;
+  shoup_q_columns_from<P, NL - 1>(acc, a, c, q);
+  q[NL - 1] = (uint32_t)acc;
+  E29<P, 3, K::LNORM> r;
+  acc = 0;
+  shoup_r_columns_from<P, 0>(acc, a, c, q, r);
+  return r;
+}
+
 // R mod p (plain; the factor that takes x R' back to x R through mul()) and R' mod p (the Montgomery one of this form)
 // as normalised limbs
 template <class P>
