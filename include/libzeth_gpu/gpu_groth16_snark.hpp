@@ -241,7 +241,9 @@ template<typename ppT> Fr<ppT> random_field_element()
 template<typename ppT> class device_proving_key_pool
 {
 public:
-    static constexpr size_t default_in_flight_per_device = 4; // measured: 2 / 4 / 8 in flight = 300 / 385 / 250 proofs/s
+    // measured (JoinSplit-shaped proof, one MI355X): 2 / 3 / 4 / 5 / 6 / 8 in flight = 390 / 443 / 439 / 363 / 335 / 341 proofs/s
+    // (from five on the callers' and lanes' host threads outnumber a GPU's share of cores)
+    static constexpr size_t default_in_flight_per_device = 4;
 
     device_proving_key_pool(
         const r1cs_gg_ppzksnark_proving_key<ppT> &pk, const std::vector<int> &devices, size_t in_flight_per_device = default_in_flight_per_device)
