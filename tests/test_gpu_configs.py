@@ -148,6 +148,31 @@ def test_bls377_proof_with_default_h_table(ctx, monkeypatch):
     dpk.free()
 
 
+def test_bls377_proof_2p20_staged_upload_and_early_lanes(ctx, monkeypatch):
+    """configs[3] at a quarter of its size, in the SHIPPED library's own configuration for large proofs: a BLS12-377
+    proof over a 2^20-point domain whose 42 MB assignment takes the four-thread staged upload, with the A and L queries
+    evaluated over its first half on the two early lanes while the second half is uploaded (prover.cuh), every query on
+    its fixed-base table -- against the C++ oracle, from the key and from a clone."""
+    import zeth_amd.lib as zl
+
+    monkeypatch.delenv("ZG_PK_TABLE_MIN", raising=False)
+    cid = 1
+    randomness = [(0x1234567890ABCDEF1234567890ABCDEF, 0x0FEDCBA0987654321FEDCBA098765432)]
+    cs, primary, aux, dpk, want = _key_and_oracle_proofs(ctx, cid, 1040000, randomness)
+    assert cs.domain_size() == 1 << 20 and 32 * len(aux) >= 32 << 20
+    n = zl.fq_bytes(cid)
+    out = ctypes.create_string_buffer(8 * n)
+    pb = ctypes.create_string_buffer(zl.encode_scalars(primary), 32 * len(primary))
+    ab = ctypes.create_string_buffer(zl.encode_scalars(aux), 32 * len(aux))
+    twin = dpk.clone()
+    for h in (dpk._h, twin._h, dpk._h):
+        zl._check(ctx._L.zg_prove(h, pb, len(primary), ab, len(aux), zl.FORM_PLAIN, zl.int_to_le(randomness[0][0], 32),
+                                  zl.int_to_le(randomness[0][1], 32), zl.FORM_PLAIN, out))
+        assert out.raw == want[0]
+    twin.free()
+    dpk.free()
+
+
 @pytest.mark.parametrize("curve", ["alt-bn128", "bls12-377"])
 def test_g2_msm_2p18_closed_form(ctx, curve):
     """configs[2]'s G2 leg at 2^18 points: P_i = (t0 + i d) G2, uniform scalars, windowed and with the fixed-base table."""
