@@ -187,7 +187,7 @@ struct ProvingKeyDev : PkBase {
   // scalars are the only dense ones of a proof (uniform field elements); A, B and L are mostly 0/1 and stay windowed.
   int H_c = 0, H_levels = 0;
   // The A, B (G1 and G2) and L queries likewise (round 3): their scalars are the witness -- mostly 0 and 1, which cost one
-  // entry each in either mode, plus the "dense" ones, which take D = 15 table digits instead of 22 windowed ones -- and
+  // entry each in either mode, plus the "dense" ones, which take D = 16 table digits instead of 22 windowed ones -- and
   // one bucket set per evaluation replaces 22 windows' worth of reductions and the host's Horner over them.
   int A_c = 0, A_levels = 0, B1_c = 0, B1_levels = 0, B2_c = 0, B2_levels = 0, L_c = 0, L_levels = 0;
   // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
@@ -326,7 +326,7 @@ struct ProvingKeyDev : PkBase {
     };
     {
       static const int h_table_c = zg_knob("ZG_PK_TABLE_C") ? atoi(zg_knob("ZG_PK_TABLE_C")) : 0;  // tuning knob
-      // Up to 2^19 points a 17-bit table (15 digits, 2^16 buckets in two groups) instead of the lone evaluation's 20 bits:
+      // Up to 2^19 points a 17-bit table (16 digits, 2^16 buckets in two groups) instead of the lone evaluation's 20 bits:
       // alone the two take the same time, inside a proof the eight times smaller reduction leaves the device to the
       // other evaluations (JoinSplit shape, four proofs in flight: 375 -> 385-398 proofs/s, latency unchanged).  From
       // 2^20 points on 20 bits win alone and inside a proof (BLS12-377, 2^20 constraints: 11.9 against 12.9 ms).
