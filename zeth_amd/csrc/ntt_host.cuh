@@ -72,6 +72,14 @@ inline uint32_t ntt_pick_tile(uint32_t n_this, uint32_t n_other) {
 // split of log m over the two passes; false when this build cannot run the size
 inline bool ntt_split(unsigned log_m, unsigned* l1, unsigned* l2) {
   *l1 = log_m <= 12 ? log_m : (log_m + 1) / 2;
+  // From 2^21 points pass A takes one stage fewer than the even split where pass B has room for it: pass A's column tiles
+  // are then two elements wide instead of one (64-byte runs), which is worth more than pass B's longer rows cost -- 2^21
+  // 0.259 -> 0.255 ms, 2^22 0.531 -> 0.521, 2^23 1.145 -> 1.116 (profiles/r3_ntt_split.jsonl; one stage MORE loses 7 %).
+  // (tuning knob ZG_NTT_L1_DELTA: pass A's share of the stages, relative to that)
+  if (log_m >= 21 && log_m - (*l1 - 1) <= 12) *l1 -= 1;
+  static const int delta = zg_knob("ZG_NTT_L1_DELTA") ? atoi(zg_knob("ZG_NTT_L1_DELTA")) : 0;
+  if (log_m > 12 && delta && (int)*l1 + delta >= 1 && (int)*l1 + delta <= 12 && log_m - (unsigned)((int)*l1 + delta) <= 12)
+    *l1 = (unsigned)((int)*l1 + delta);
   *l2 = log_m - *l1;
   return *l1 <= 12;
 }
