@@ -26,3 +26,18 @@ extern thread_local int zg_crumb_slot;
 #define ZG_CRUMB(text) ((void)0)
 #define ZG_CRUMB_SLOT(i) ((void)0)
 #endif
+
+
+// Issue priority of a kernel's waves among the waves that share its SIMD (s_setprio, 0-3; the hardware default is 0).
+// Short latency-bound kernels (scans, unit tables, the reductions' chains) and the kernels of a proof's longest chain
+// (constraint evaluation, transforms) raise theirs: inside a proof they share CUs with the accumulation kernels of the
+// other evaluations, whose waves otherwise take three issue slots in four.  This is per wave and inside the CU -- it has
+// nothing to do with stream priorities (prover.cuh), which stall the runtime.
+#ifndef ZG_WAVE_PRIO_ON
+#define ZG_WAVE_PRIO_ON 1
+#endif
+#if ZG_WAVE_PRIO_ON && defined(__HIP_DEVICE_COMPILE__)
+#define ZG_WAVE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define ZG_WAVE_PRIO(n) ((void)0)
+#endif

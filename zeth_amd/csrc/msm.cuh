@@ -358,6 +358,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 static __global__ void __launch_bounds__(256) k_zero_u32(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b,
                                                           size_t nb_, uint32_t* __restrict__ one_word, uint32_t* __restrict__ c,
                                                           size_t nc /* third array (table mode's group counts) or 0 */) {
+  ZG_WAVE_PRIO(3);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < na) a[i] = 0;
   if (i < nb_) b[i] = 0;
@@ -439,6 +440,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t* __restrict__ lencur /* [W][UNIT_CLASS_STRIDE]: first slot of each length class */,
                                                 uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */,
                                                 const uint32_t* __restrict__ gstart /* table mode: first entry of each bucket group; else null */) {
+  ZG_WAVE_PRIO(3);
   __shared__ uint32_t lh[UNIT_CLASSES + 1], wtot[16][3];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t per_wave = (nb + 15) / 16;
@@ -757,6 +759,7 @@ static __global__ void __launch_bounds__(256) k_units(const uint32_t* __restrict
                                                 uint32_t* __restrict__ order /* [W][cap]: unit ids, longest first */,
                                                 uint32_t* __restrict__ heavy /* [0] = count, then ids of heavy buckets */,
                                                 uint32_t smax) {
+  ZG_WAVE_PRIO(3);
   __shared__ uint32_t lc[UNIT_CLASSES], gb[UNIT_CLASSES];
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = g < (size_t)nb * W;
@@ -798,6 +801,7 @@ static __global__ void __launch_bounds__(256) k_units_heavy(const uint32_t* __re
                                                       uint32_t nb, uint32_t L, uint32_t cap, UnitDesc* __restrict__ units,
                                                       uint32_t* __restrict__ lencur, uint32_t* __restrict__ order,
                                                       const uint32_t* __restrict__ heavy, uint32_t smax) {
+  ZG_WAVE_PRIO(3);
   const uint32_t nheavy = heavy[0];
   for (uint32_t hi = blockIdx.y; hi < nheavy; hi += gridDim.y) {
     const uint32_t g = heavy[1 + hi];
@@ -1003,6 +1007,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_combine_light(const uint32_t* __restrict__ wunits, uint32_t W, uint32_t nb,
                                                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
                                                         uint32_t L, XYZZ<F>* __restrict__ part, uint32_t smax) {
+  ZG_WAVE_PRIO(3);
   if (wunits[W] <= 1) return;  // no bucket has more than one unit
   const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
   if (b >= nb) return;
@@ -1022,6 +1027,7 @@ __global__ void __launch_bounds__(quad_block<F>()) k_combine_tree(const uint32_t
                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ufirst,
                                                                    uint32_t L, uint32_t stride, XYZZ<F>* __restrict__ part,
                                                                    const uint32_t* __restrict__ max_units /* most units in any bucket */) {
+  ZG_WAVE_PRIO(3);
   // chunk slots beyond the longest bucket have nothing to do in any heavy bucket
   if ((size_t)blockIdx.x * COMBINE_CHUNK * stride >= max_units[0]) return;
   using Q = QuadOps<F>;
@@ -1057,6 +1063,7 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
                                                   uint32_t L, uint32_t W, XYZZ<F>* __restrict__ seg,
                                                   XYZZ<F>* __restrict__ seg_plain /* table mode: unweighted segment sums; else null */,
                                                   uint32_t weighted /* 0 (table mode): seg gets sum (i + 1) B_{jk+i} only */) {
+  ZG_WAVE_PRIO(3);
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
   if (g >= T * W) return;
   const uint32_t w = g / T, j = g % T;
@@ -1093,6 +1100,7 @@ __global__ void __launch_bounds__(128) k_reduce1(const uint32_t* __restrict__ cn
 template <class F>
 __global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict__ seg, uint32_t T, uint32_t n, uint32_t stride,
                                                             int final) {
+  ZG_WAVE_PRIO(3);
   XYZZ<F>* s = seg + (size_t)blockIdx.x * T + (size_t)blockIdx.y * n * stride;
   using Q = QuadOps<F>;
   const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
@@ -1134,6 +1142,7 @@ __global__ void __launch_bounds__(quad_block<F>()) k_reduce2(XYZZ<F>* __restrict
 template <class F>
 __global__ void __launch_bounds__(quad_block<F>()) k_bitsum(XYZZ<F>* __restrict__ X, XYZZ<F>* __restrict__ Y, uint32_t lo, uint32_t hi,
                                                            XYZZ<F>* __restrict__ rows /* null except in the last launch */) {
+  ZG_WAVE_PRIO(3);
   using Q = QuadOps<F>;
   const uint32_t qi = threadIdx.x >> 2, nq = blockDim.x >> 2, q = threadIdx.x & 3u;
   XYZZ<F>* x = X + ((size_t)blockIdx.x << hi);

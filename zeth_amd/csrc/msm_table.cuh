@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) k_table_count(const uint32_t* __restrict_
 static __global__ void __launch_bounds__(64) k_table_starts(const uint32_t* __restrict__ gcnt, uint32_t W,
                                                             uint32_t* __restrict__ gstart /* [W + 1] */,
                                                             uint32_t* __restrict__ gcursor /* [W] */) {
+  ZG_WAVE_PRIO(3);
   if (threadIdx.x != 0) return;
   uint32_t run = 0;
   for (uint32_t w = 0; w < W; w++) {

@@ -30,6 +30,7 @@
 
 #include "field.cuh"
 #include "field29.cuh"
+#include "knobs.h"
 
 namespace zg {
 
@@ -293,6 +294,7 @@ __device__ __forceinline__ uint32_t ntt_tile_of_block(uint32_t b, uint32_t nbloc
 template <class Fr, int IN_MODE, int RMAX>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, NttTables<Fr> T, int inverse, unsigned log_tc,
                                                             size_t vstride) {
+  ZG_WAVE_PRIO(2);
   constexpr bool COSET_IN = IN_MODE == 1;
   constexpr bool QAP_IN = IN_MODE == 2;
   extern __shared__ uint32_t lds[];
@@ -381,6 +383,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_a(Fr* __restrict__ a, 
 template <class Fr, int OUT_MODE, int RMAX>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass_b(const Fr* __restrict__ a, Fr* __restrict__ out, NttTables<Fr> T,
                                                             int inverse, unsigned log_tr, size_t vstride) {
+  ZG_WAVE_PRIO(2);
   extern __shared__ uint32_t lds[];
   using N = Ntt29<Fr>;
   using P = typename N::P;

@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) k_build_w(const Fr* __restrict__ primary,
   if (i >= hi || i > n_primary + n_aux) return;
   Fr x;
   if (i == 0) {
+  ZG_WAVE_PRIO(2);
     x = Fr::one();
   } else {
     x = (i - 1 < n_primary) ? glob_get(primary + (i - 1)) : glob_get(aux + (i - 1 - n_primary));
@@ -130,6 +131,7 @@ struct SpmvMatrices {
 template <class Fr>
 __global__ void __launch_bounds__(256) k_spmv(SpmvMatrices M, const Fr* __restrict__ w, size_t nc, size_t m, size_t extra_rows,
                                                Fr* __restrict__ out) {
+  ZG_WAVE_PRIO(2);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const unsigned k = blockIdx.y;
