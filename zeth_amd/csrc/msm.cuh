@@ -441,13 +441,18 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
                                                 uint32_t* __restrict__ ffirst /* [W][nb]: full-length units before the bucket */,
                                                 const uint32_t* __restrict__ gstart /* table mode: first entry of each bucket group; else null */) {
   ZG_WAVE_PRIO(3);
-  __shared__ uint32_t lh[UNIT_CLASSES + 1], wtot[16][3];
+  // the histogram of unit length classes in SCAN_HIST_COPIES copies, lane l counting into copy l % COPIES: bucket loads
+  // cluster around their mean, so a wave's 64 increments fall on a handful of classes, and increments of one address
+  // are served one after the other (k_scan without them: 35 instead of 47-64 us, profiles/r3_k_scan.jsonl)
+  constexpr uint32_t COPIES = 8;
+  __shared__ uint32_t lh[COPIES][UNIT_CLASSES + 1], wtot[16][3], csum[16];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  uint32_t* const my_lh = lh[lane % COPIES];
   const uint32_t per_wave = (nb + 15) / 16;
   const uint32_t lo = wv * per_wave < nb ? wv * per_wave : nb;
   const uint32_t hi = lo + per_wave < nb ? lo + per_wave : nb;
   const uint32_t* __restrict__ c = cnt + (size_t)w * nb;
-  for (uint32_t q = tid; q <= UNIT_CLASSES; q += blockDim.x) lh[q] = 0;
+  for (uint32_t q = tid; q < COPIES * (UNIT_CLASSES + 1); q += blockDim.x) (&lh[0][0])[q] = 0;
   __syncthreads();
   // the wave's counts, read once with all loads in flight together (a load per loop iteration in each of the two passes
   // below was 64 dependent round trips to L2: most of this kernel's 65 us)
@@ -469,8 +474,8 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
     sb += nu;
     sc += fu;
     mx = nu > mx ? nu : mx;
-    if (fu) atomicAdd(&lh[UNIT_CLASSES], fu);
-    if (v % L) atomicAdd(&lh[unit_class(v % L, L)], 1u);
+    if (fu) atomicAdd(&my_lh[UNIT_CLASSES], fu);
+    if (v % L) atomicAdd(&my_lh[unit_class(v % L, L)], 1u);
   }
 #pragma unroll
   for (uint32_t d = 32; d >= 1; d >>= 1) {
@@ -487,11 +492,26 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict
     if (mx > 1) atomicMax(&wunits[gridDim.x], mx);
   }
   __syncthreads();
-  // slot ranges of the length classes, longest first (full-length units, then the partial classes from longest to shortest)
-  for (uint32_t cls = tid; cls <= UNIT_CLASSES; cls += blockDim.x) {
-    uint32_t before = 0;
-    for (uint32_t q = cls + 1; q <= UNIT_CLASSES; q++) before += lh[q];
-    lencur[(size_t)w * UNIT_CLASS_STRIDE + cls] = before;
+  // slot ranges of the length classes, longest first (full-length units, then the partial classes from longest to
+  // shortest): lencur[cls] = the units of every class above cls.  One class per thread, taken from the top (thread t has
+  // class UNIT_CLASSES - 1 - t), an inclusive scan over the threads (every thread summing the classes above its own was
+  // 8-12 us of this kernel)
+  {
+    static_assert(UNIT_CLASSES == 1024, "one class per thread of the block");
+    const uint32_t cls = UNIT_CLASSES - 1u - tid;
+    uint32_t mine = 0, full = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < COPIES; k++) {
+      mine += lh[k][cls];
+      full += lh[k][UNIT_CLASSES];
+    }
+    const uint32_t incl = wave_inclusive_scan(mine);
+    if (lane == 63) csum[wv] = incl;
+    __syncthreads();
+    uint32_t above = full;  // the full-length units come first
+    for (uint32_t q = 0; q < wv; q++) above += csum[q];
+    lencur[(size_t)w * UNIT_CLASS_STRIDE + cls] = above + incl - mine;
+    if (tid == 0) lencur[(size_t)w * UNIT_CLASS_STRIDE + UNIT_CLASSES] = 0;
   }
   // pass 2: exclusive prefixes
   uint32_t ea = 0, eb = 0, ef = 0, ta = 0, tb = 0;
