@@ -200,7 +200,7 @@ struct ProvingKeyDev : PkBase {
   zg_ctx* lane[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   LaneWorker* worker[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool early = false;
-  hipEvent_t w_half = nullptr;
+  hipEvent_t w_half = nullptr, bsc_ready = nullptr;
   // page-locked staging of the parallel upload: two halves per lane, and the events that say a half's copy has left it
   static constexpr size_t STAGE_BYTES = (size_t)2 << 20;
   // (debug builds: ZG_PAR_UPLOAD_MIN_KB / ZG_PAR_STAGE_KB shrink the threshold and the staging halves, so that a test-sized
@@ -226,6 +226,7 @@ struct ProvingKeyDev : PkBase {
       if (l) zg_ctx_destroy(l);
     if (w_ready) hipEventDestroy(w_ready);
     if (w_half) hipEventDestroy(w_half);
+    if (bsc_ready) hipEventDestroy(bsc_ready);
     if (owns_key) {
       for (auto& M : mat) {
         hipFree(M.row_ptr);
@@ -399,6 +400,7 @@ struct ProvingKeyDev : PkBase {
        // reallocation, not scratch, not GPU_MAX_HW_QUEUES; a pure-HIP reproducer of the same shape never stalls.
     for (int i = 4; i < n_lanes; i++) worker[i] = new LaneWorker();
     ZG_HIP(hipEventCreateWithFlags(&w_half, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&bsc_ready, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
       worker[i] = new LaneWorker();
       if ((num_vars * sizeof(Fr)) >= par_upload_min) {
@@ -621,21 +623,31 @@ struct ProvingKeyDev : PkBase {
       ZG_TRY(load_assignment(primary, n_primary, aux, n_aux, form));
     stamp("assignment queued");
     hipStream_t st = ctx->stream;
-    if (B_len) hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
+    static const int hold = zg_knob("ZG_PROVE_HOLD") ? atoi(zg_knob("ZG_PROVE_HOLD")) : 0;
+    static const int lane_wait = zg_knob("ZG_LANE_WAIT") ? atoi(zg_knob("ZG_LANE_WAIT")) : 0;
+    // The B query's scalars are a gather over 1||w that only the two B lanes read: it runs on lane 0's stream (lane 3
+    // waits for it through an event), not ahead of the constraint evaluation on the main stream, whose chain is the
+    // proof's longest (35 us of it at JoinSplit scale).  (The debug builds' hold / host-wait modes keep it on the main stream.)
+    const bool gather_on_lane = B_len && hold == 0 && lane_wait == 0;
+    if (B_len && !gather_on_lane)
+      hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
     // The A, B (G2 and G1) and L evaluations depend only on 1||w: they run on four side streams ("lanes", each a
     // context with its own workspace) while the main stream computes H's coefficients and then the H evaluation.
     // ZG_PROVE_HOLD = 1 | 2 | 3 (measurement knob): the lanes start only after that many parts of the H chain's
     // transforms have run (0: as soon as 1||w is there)
-    static const int hold = zg_knob("ZG_PROVE_HOLD") ? atoi(zg_knob("ZG_PROVE_HOLD")) : 0;
     int h_status = ZG_OK;
     if (hold >= 1 && hold <= 3) h_status = qap_h(0, hold - 1);
     ZG_HIP(hipEventRecord(w_ready, st));
     // (debug builds: ZG_LANE_WAIT = 1 waits for 1||w on the host instead of in the lanes' queues)
-    static const int lane_wait = zg_knob("ZG_LANE_WAIT") ? atoi(zg_knob("ZG_LANE_WAIT")) : 0;
     if (lane_wait == 1) {
       ZG_HIP(hipEventSynchronize(w_ready));
     } else {
       for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
+    }
+    if (gather_on_lane) {
+      hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, lane[0]->stream, w, B_idx, B_len, bsc);
+      ZG_HIP(hipEventRecord(bsc_ready, lane[0]->stream));
+      ZG_HIP(hipStreamWaitEvent(lane[3]->stream, bsc_ready, 0));
     }
     XYZZ<Fq> At, Bt1, Ht, Lt;
     XYZZ<Fq2T> Bt2;
