@@ -208,6 +208,8 @@ def test_adapter_proofs_in_flight_through_the_pool(curve, tmp_path):
     words = out.stdout.split()
     peak, done = int(words[words.index("peak_in_flight") + 1]), int(words[words.index("proofs") + 1])
     assert done == threads * per and 2 <= peak <= 4, out.stdout
+    # pool.warm_up(): all three provers of a fresh pool created and used once (3 held at once, 3 + 1 proofs), same proof after
+    assert "warm_up provers 3 proofs 4 same 1" in out.stdout, out.stdout
     for k in range(threads * per):
         want = M.proof_to_bytes(C, M.prove(C, pk, primary, aux, r + k, s + 2 * k + 1))
         assert (tmp_path / ("p.%d" % k)).read_bytes() == want, "proof %d" % k

@@ -353,6 +353,13 @@ template<typename ppT> int cmd_prove_concurrent(char **argv)
         snarkT::proof_write_bytes(stateless[t], out_s);
     }
     std::cout << "peak_in_flight " << pool.peak_in_flight() << " proofs " << pool.proofs_completed() << "\n";
+    {
+        // warm_up(): every prover of a fresh pool exists and has proved once, and proves the same proof afterwards
+        device_proving_key_pool<ppT> warm(pk, {0}, 3);
+        warm.warm_up(primary, auxiliary);
+        const bool same = warm.prove(primary, auxiliary, add_small<ppT>(r0, 0), add_small<ppT>(s0, 1)) == proofs[0];
+        std::cout << "warm_up provers " << warm.peak_in_flight() << " proofs " << warm.proofs_completed() << " same " << (same ? 1 : 0) << "\n";
+    }
     return 0;
 }
 
