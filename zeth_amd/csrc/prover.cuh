@@ -125,6 +125,19 @@ struct SpmvMatrices {
   const void* val[3];
 };
 
+// Most coefficients of a boolean-heavy circuit are +1 or -1.  Once per key the column indices of those entries are
+// tagged in their two top bits (1: the coefficient is one, 2: minus one; indices are below 2^30), so that the constraint
+// evaluation neither loads nor multiplies their 32-byte coefficients.
+static constexpr uint32_t CSR_COL_MASK = (1u << 30) - 1u;
+template <class Fr>
+__global__ void __launch_bounds__(256) k_csr_tag_units(uint32_t* __restrict__ col, const Fr* __restrict__ val /* Montgomery */, size_t nnz) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nnz) return;
+  const Fr v = glob_get(val + t);
+  if (v == Fr::one()) col[t] |= 1u << 30;
+  else if (v == Fr::neg(Fr::one())) col[t] |= 2u << 30;
+}
+
 // out[k m + i] = <row_i of matrix k, w> for i < nc; matrix A (k = 0) additionally carries w_0..w_num_inputs in rows
 // nc..nc+num_inputs (libsnark r1cs_to_qap: the extra constraints that make the A polynomials linearly independent);
 // the rest of each m-sized vector is zero.
@@ -140,14 +153,12 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvMatrices M, const Fr* __restri
   const Fr* __restrict__ val = static_cast<const Fr*>(M.val[k]);
   Fr acc = Fr::zero();
   if (i < nc) {
-    // most coefficients of a boolean-heavy circuit are +1 or -1: those terms need no multiplication
-    const Fr one = Fr::one(), minus_one = Fr::neg(Fr::one());
     for (uint64_t t = row_ptr[i]; t < row_ptr[i + 1]; t++) {
-      const Fr v = glob_get(val + t);
-      const Fr x = glob_get(w + col[t]);
-      if (v == one) acc = Fr::add(acc, x);
-      else if (v == minus_one) acc = Fr::sub(acc, x);
-      else acc = Fr::add(acc, Fr::mul(v, x));
+      const uint32_t c = col[t], kind = c >> 30;  // k_csr_tag_units
+      const Fr x = glob_get(w + (c & CSR_COL_MASK));
+      if (kind == 1u) acc = Fr::add(acc, x);
+      else if (kind == 2u) acc = Fr::sub(acc, x);
+      else acc = Fr::add(acc, Fr::mul(glob_get(val + t), x));
     }
   } else if (k == 0 && i - nc < extra_rows) {
     acc = glob_get(w + (i - nc));
@@ -262,6 +273,7 @@ struct ProvingKeyDev : PkBase {
     }
     if (v->A_len != num_vars + 1 || v->H_len != m - 1 || v->L_len != num_vars - num_inputs || v->B_len > num_vars + 1)
       return ZG_ERR_INVALID_ARGUMENT;
+    if (num_vars >= CSR_COL_MASK) return ZG_ERR_UNSUPPORTED;  // column indices carry two tag bits (k_csr_tag_units)
     const zg_r1cs_matrix* src[3] = {&v->a, &v->b, &v->c};
     const int plain = v->form == ZG_FORM_PLAIN;
     hipStream_t st = ctx->stream;
@@ -287,6 +299,8 @@ struct ProvingKeyDev : PkBase {
       mat[k].val = val;
       if (plain && nnz)
         hipLaunchKernelGGL((k_fr_convert<Fr>), dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, val, nnz, 1);
+      if (nnz)
+        hipLaunchKernelGGL((k_csr_tag_units<Fr>), dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, mat[k].col, val, nnz);
     }
     const GroupOps* o1 = zg_group_ops(curve, ZG_GROUP_G1);
     const GroupOps* o2 = zg_group_ops(curve, ZG_GROUP_G2);
