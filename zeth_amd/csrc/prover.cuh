@@ -204,7 +204,9 @@ struct ProvingKeyDev : PkBase {
   // one bucket set per evaluation replaces 22 windows' worth of reductions and the host's Horner over them.
   int A_c = 0, A_levels = 0, B1_c = 0, B1_levels = 0, B2_c = 0, B2_levels = 0, L_c = 0, L_levels = 0;
   // per-proof scratch (device): 1||w, three evaluation vectors, one transform buffer, gathered B scalars, inputs
-  Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr;
+  // (`assign` = the assignment as the caller passed it, behind one more element that holds the plain integer 1: with a
+  // plain assignment the witness lanes read their scalars 1 || w straight from `assign_base`)
+  Fr *w = nullptr, *ev[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr, *bsc = nullptr, *assign = nullptr, *assign_base = nullptr;
   Fr z_inv;
   // lanes 0-3: the B (G2), A, L and B (G1) evaluations; lanes 4, 5 (large proofs only, `early`): the A and L evaluations
   // over the first half of the assignment, started while the second half is still crossing PCIe
@@ -246,7 +248,7 @@ struct ProvingKeyDev : PkBase {
       }
       hipFree(A); hipFree(B1); hipFree(B2); hipFree(H); hipFree(L); hipFree(B_idx);
     }
-    hipFree(w); hipFree(ev[0]); hipFree(tmp); hipFree(bsc); hipFree(assign);
+    hipFree(w); hipFree(ev[0]); hipFree(tmp); hipFree(bsc); hipFree(assign_base);
   }
 
   template <class T>
@@ -431,7 +433,13 @@ struct ProvingKeyDev : PkBase {
     ev[2] = ev[1] + m;
     ZG_HIP(hipMalloc((void**)&tmp, 3 * m * sizeof(Fr)));
     ZG_HIP(hipMalloc((void**)&bsc, (B_len ? B_len : 1) * sizeof(Fr)));
-    ZG_HIP(hipMalloc((void**)&assign, (num_vars ? num_vars : 1) * sizeof(Fr)));
+    ZG_HIP(hipMalloc((void**)&assign_base, (num_vars + 1) * sizeof(Fr)));
+    assign = assign_base + 1;
+    {
+      Fr plain_one = Fr::zero();
+      plain_one.v[0] = 1;
+      ZG_HIP(hipMemcpy(assign_base, &plain_one, sizeof(Fr), hipMemcpyHostToDevice));
+    }
     // 1 / Z(g) = 1 / (g^m - 1)   (divide_by_Z_on_coset)
     using P = typename Fr::Params;
     Fr g = fr_from_limbs<Fr>(P::GEN_MONT);
@@ -597,6 +605,11 @@ struct ProvingKeyDev : PkBase {
     // Large proofs (`early`): the A and L evaluations are split at the middle of the assignment.  The first halves are
     // queued on lanes 4 and 5 as soon as the first half of the assignment is on the device, by their own threads, while
     // this thread goes on to upload the second half; lanes 1 and 2 then take the second halves (MsmTable::first).
+    // The witness lanes' scalars: a PLAIN assignment is read as the caller passed it (1 || w with the plain one in front,
+    // `assign_base`) -- the evaluations recode plain integers, so the Montgomery copy that k_build_w makes for the
+    // constraint evaluation would only be converted back, twice per scalar and evaluation
+    const Fr* const lane_w = form == ZG_FORM_PLAIN ? assign_base : w;
+    const int lane_mont = form == ZG_FORM_PLAIN ? 0 : 1;
     size_t a_split = 0, l_split = 0;  // bases [0, split) go to the early lanes
     int early_status[2] = {ZG_OK, ZG_OK};
     struct JoinEarly {  // the early lanes' threads use this frame: they are joined on every way out, and after an error
@@ -613,21 +626,21 @@ struct ProvingKeyDev : PkBase {
       a_split = 1 + n_primary + h;
       l_split = h;
       for (int i = 4; i < 6; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_half, 0));
-      worker[4]->submit([this, o1, a_split, &early_status] {
+      worker[4]->submit([this, o1, a_split, lane_w, lane_mont, &early_status] {
         if (hipSetDevice(ctx->device) != hipSuccess) {
           early_status[0] = ZG_ERR_HIP;
           return;
         }
         const MsmTable t{A_len, 0, A_c, A_levels};
-        early_status[0] = o1->msm_launch(lane[4], A, (const uint32_t*)w, a_split, 1, 0, &t);
+        early_status[0] = o1->msm_launch(lane[4], A, (const uint32_t*)lane_w, a_split, lane_mont, 0, &t);
       });
-      worker[5]->submit([this, o1, l_split, &early_status] {
+      worker[5]->submit([this, o1, l_split, lane_w, lane_mont, &early_status] {
         if (hipSetDevice(ctx->device) != hipSuccess) {
           early_status[1] = ZG_ERR_HIP;
           return;
         }
         const MsmTable t{L_len, 0, L_c, L_levels};
-        early_status[1] = o1->msm_launch(lane[5], L, (const uint32_t*)(w + num_inputs + 1), l_split, 1, 0, &t);
+        early_status[1] = o1->msm_launch(lane[5], L, (const uint32_t*)(lane_w + num_inputs + 1), l_split, lane_mont, 0, &t);
       });
       return ZG_OK;
     };
@@ -644,7 +657,7 @@ struct ProvingKeyDev : PkBase {
     // proof's longest (35 us of it at JoinSplit scale).  (The debug builds' hold / host-wait modes keep it on the main stream.)
     const bool gather_on_lane = B_len && hold == 0 && lane_wait == 0;
     if (B_len && !gather_on_lane)
-      hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, w, B_idx, B_len, bsc);
+      hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, st, lane_w, B_idx, B_len, bsc);
     // The A, B (G2 and G1) and L evaluations depend only on 1||w: they run on four side streams ("lanes", each a
     // context with its own workspace) while the main stream computes H's coefficients and then the H evaluation.
     // ZG_PROVE_HOLD = 1 | 2 | 3 (measurement knob): the lanes start only after that many parts of the H chain's
@@ -659,7 +672,7 @@ struct ProvingKeyDev : PkBase {
       for (int i = 0; i < 4; i++) ZG_HIP(hipStreamWaitEvent(lane[i]->stream, w_ready, 0));
     }
     if (gather_on_lane) {
-      hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, lane[0]->stream, w, B_idx, B_len, bsc);
+      hipLaunchKernelGGL((k_gather<Fr>), dim3((unsigned)((B_len + 255) / 256)), dim3(256), 0, lane[0]->stream, lane_w, B_idx, B_len, bsc);
       ZG_HIP(hipEventRecord(bsc_ready, lane[0]->stream));
       ZG_HIP(hipStreamWaitEvent(lane[3]->stream, bsc_ready, 0));
     }
@@ -719,10 +732,10 @@ struct ProvingKeyDev : PkBase {
       const MsmTable* tab = tabs[i].D ? &tabs[i] : nullptr;
       const int c = tab ? 0 : width(dense_hint[i]);
       switch (i) {
-        case 0: lane_status[0] = o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, 1, c, tab); break;
-        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)(w + a_split), A_len - a_split, 1, c, tab); break;
-        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(w + num_inputs + 1 + l_split), L_len - l_split, 1, c, tab); break;
-        default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, 1, c, tab); break;
+        case 0: lane_status[0] = o2->msm_launch(lane[0], B2, (const uint32_t*)bsc, B_len, lane_mont, c, tab); break;
+        case 1: lane_status[1] = o1->msm_launch(lane[1], A, (const uint32_t*)(lane_w + a_split), A_len - a_split, lane_mont, c, tab); break;
+        case 2: lane_status[2] = o1->msm_launch(lane[2], L, (const uint32_t*)(lane_w + num_inputs + 1 + l_split), L_len - l_split, lane_mont, c, tab); break;
+        default: lane_status[3] = o1->msm_launch(lane[3], B1, (const uint32_t*)bsc, B_len, lane_mont, c, tab); break;
       }
     };
     static const bool serial_queue = zg_knob("ZG_PROVE_SERIAL_QUEUE") != nullptr;  // measurement knob: one queueing thread
