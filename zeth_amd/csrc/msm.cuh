@@ -357,13 +357,21 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 
 static __global__ void __launch_bounds__(256) k_zero_u32(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b,
                                                           size_t nb_, uint32_t* __restrict__ one_word, uint32_t* __restrict__ c,
-                                                          size_t nc /* third array (table mode's group counts) or 0 */) {
+                                                          size_t nc /* third array (table mode's group counts) or 0 */,
+                                                          uint32_t* __restrict__ gse /* two-ended table mode (msm_table.cuh) or null */,
+                                                          uint32_t entries) {
   ZG_WAVE_PRIO(3);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < na) a[i] = 0;
   if (i < nb_) b[i] = 0;
   if (i < nc) c[i] = 0;
   if (i == 0) one_word[0] = 0;
+  if (i == 0 && gse) {  // starts {0, E}, ends {0, E}: group 0 grows up from 0, group 1 down from E
+    gse[0] = 0;
+    gse[1] = entries;
+    gse[2] = 0;
+    gse[3] = entries;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

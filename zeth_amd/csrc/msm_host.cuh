@@ -271,8 +271,14 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->prof_begin();
   ctx->mark("digits");
   ZG_CRUMB("msm_launch: first kernel launch (k_zero_u32)");
+  // table mode with at most two bucket groups: the two-ended layout (msm_table.cuh), no counting pass
+  static const bool no_two_ended = zg_knob("ZG_MSM_NO_TWO_ENDED") != nullptr;  // measurement knob
+  const bool two_ended = tab && p.W <= 2 && !no_two_ended;
+  uint32_t* gse = two_ended ? gcnt : (uint32_t*)nullptr;  // (the counts' array is free in this layout)
+  const uint32_t* gstart_r = two_ended ? gse : gstart;
+  const uint32_t* gend_r = two_ended ? gse + 2 : gstart + 1;
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, st, cnt, WB, wunits,
-                     (size_t)(p.W + 1 + 64), heavy, gcnt, (size_t)(tab ? 129 : 0));
+                     (size_t)(p.W + 1 + 64), heavy, gcnt, (size_t)(tab && !two_ended ? 129 : 0), gse, (uint32_t)WN);
   uint32_t* dense_counters = ctx->want_dense ? wunits + p.W + 1 : (uint32_t*)nullptr;
   if (tab) {
     // level 0 of the sort: entries by bucket group
@@ -282,27 +288,29 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
     if (cblocks > 2048) cblocks = 2048;
     // (k_table_starts stays a launch of its own: folding it into the last workgroup of k_table_count needs a device-wide
     // fence per workgroup, which on this part writes back and invalidates an XCD's L2 -- digits phase 0.78 -> 1.07 ms)
-    hipLaunchKernelGGL((k_table_count<Fr>), dim3((unsigned)cblocks), dim3(256), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K,
-                       (uint32_t)p.W - 1u, gcnt, dense_counters);
-    hipLaunchKernelGGL(k_table_starts, dim3(1), dim3(64), 0, st, gcnt, (uint32_t)p.W, gstart, gcursor);
+    if (!two_ended) {
+      hipLaunchKernelGGL((k_table_count<Fr>), dim3((unsigned)cblocks), dim3(256), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K,
+                         (uint32_t)p.W - 1u, gcnt, dense_counters);
+      hipLaunchKernelGGL(k_table_starts, dim3(1), dim3(64), 0, st, gcnt, (uint32_t)p.W, gstart, gcursor);
+    }
     const dim3 sgrid((unsigned)((n + tile_scalars - 1) / tile_scalars));
     if (p.c == 22 && p.D == msm_table_digits(Fr::Params::BITS, 22))
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 22>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
-                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, gse, fent, fkey);
     else if (p.c == 20 && p.D == msm_table_digits(Fr::Params::BITS, 20))
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 20>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
-                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, gse, fent, fkey);
     else if (p.c == 16 && p.D == msm_table_digits(Fr::Params::BITS, 16))
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 16>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
-                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, gse, fent, fkey);
     else if (p.c == 17 && p.D == msm_table_digits(Fr::Params::BITS, 17))  // (the prover's tables up to 2^19 points)
       hipLaunchKernelGGL((k_table_scatter_static<Fr, 17>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.K, p.gbits,
-                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, gse, fent, fkey);
     else
       hipLaunchKernelGGL((k_table_scatter<Fr>), sgrid, dim3(1024), 0, st, d_scalars, n, scalars_mont, p.c, p.D, p.K, p.gbits,
-                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, fent, fkey);
+                         (uint32_t)p.W, tile_scalars, (uint32_t)tab->N, (uint32_t)tab->first, gcursor, gse, fent, fkey);
     ctx->mark("hist");
-    hipLaunchKernelGGL(k_hist_table, dim3(p.nchunk, p.W), dim3(1024), lds, st, fkey, gstart, p.nb, cnt);
+    hipLaunchKernelGGL(k_hist_table, dim3(p.nchunk, p.W), dim3(1024), lds, st, fkey, gstart_r, gend_r, p.nb, cnt);
   } else {
     hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, scalars_mont,
                        p.c, p.W, p.K, dig, dense_counters);
@@ -312,7 +320,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
   ctx->mark("scan");
   ZG_CRUMB("msm_launch: k_scan launch");
   hipLaunchKernelGGL(k_scan, dim3(p.W), dim3(1024), 0, st, cnt, n, p.nb, p.L, p.cap, cursor, boff, ufirst, wunits, nhi,
-                     cursor1, pstart, lencur, ffirst, gstart);
+                     cursor1, pstart, lencur, ffirst, tab ? gstart_r : gstart);
   ctx->mark("scatter");
   // Window groups (experiment, off unless ZG_MSM_SPLIT is set): the top `g0` windows are sorted first and accumulated at
   // once while the remaining windows are sorted on a second stream.  Measured at 2^24 points: 35.0 ms against 30.4 ms
@@ -330,7 +338,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
         size_t t1 = (2 * per_group + SORT_TILE1T - 1) / SORT_TILE1T;
         if (t1 < 1) t1 = 1;
         if (t1 > 8192) t1 = 8192;
-        hipLaunchKernelGGL(k_scatter_hi_table, dim3((unsigned)t1, cntw), dim3(SORT_WG), 0, s, fent, fkey, gstart, nhi, cursor1, mid_ent,
+        hipLaunchKernelGGL(k_scatter_hi_table, dim3((unsigned)t1, cntw), dim3(SORT_WG), 0, s, fent, fkey, gstart_r, gend_r, nhi, cursor1, mid_ent,
                            mid_lo);
         size_t tiles = (2 * per_group / nhi + SORT_TILE2 - 1) / SORT_TILE2;
         if (tiles < 1) tiles = 1;
@@ -338,7 +346,7 @@ int msm_launch(zg_ctx* ctx, const void* d_pts, const uint32_t* d_scalars, size_t
         hipLaunchKernelGGL(k_scatter_lo, dim3((unsigned)tiles, nhi, cntw), dim3(SORT_WG), 0, s, mid_ent, mid_lo, pstart, nhi, p.nb,
                            cursor, sorted, w0);
       } else {
-        hipLaunchKernelGGL(k_scatter_table, dim3(p.nchunk, p.W), dim3(1024), lds, s, fent, fkey, gstart, p.nb, cursor, sorted);
+        hipLaunchKernelGGL(k_scatter_table, dim3(p.nchunk, p.W), dim3(1024), lds, s, fent, fkey, gstart_r, gend_r, p.nb, cursor, sorted);
       }
     } else if (nhi) {
       hipLaunchKernelGGL(k_scatter_hi, dim3((unsigned)((n + SORT_TILE1 - 1) / SORT_TILE1), cntw), dim3(1024), 0, s, dig, n, nhi,

@@ -54,13 +54,24 @@ static __global__ void __launch_bounds__(64) k_table_starts(const uint32_t* __re
   gstart[W] = run;
 }
 
+// Two-ended layout (tables of one or two bucket groups, c <= 17: the prover's queries up to 2^19 points).  The level-0
+// partition needs every group's start, i.e. a counting pass over the scalars before it (k_table_count, k_table_starts).
+// With at most two groups it does not: group 0 fills the entry array from its front and group 1 from its back, each
+// through one cursor, and the cursors ARE the groups' end and start afterwards -- gse[0..1] = starts {0, cursor of group
+// 1}, gse[2..3] = ends {cursor of group 0, E}.  Two launches fewer at the head of every such evaluation (~75 us of the
+// H chain inside a proof).  `gse` is null in the general layout, where gcursor[] holds the counted starts.
+__device__ __forceinline__ uint32_t table_claim(uint32_t* __restrict__ gcursor, uint32_t* __restrict__ gse, uint32_t g, uint32_t v) {
+  if (!gse) return atomicAdd(&gcursor[g], v);
+  return g == 0 ? atomicAdd(&gse[2], v) : atomicSub(&gse[1], v) - v;
+}
+
 // One tile of scalars per workgroup, one scalar per lane: bin the tile's entries by bucket group in LDS, claim a run
 // per group, copy out.  Entry = (j * N + first + i) | sign << 31 (index into the table), key = bucket within the group.
 template <class Fr>
 __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int D,
                                                          AddConst K, int gbits, uint32_t W, uint32_t tile_scalars,
                                                          uint32_t table_n, uint32_t first, uint32_t* __restrict__ gcursor,
-                                                         uint32_t* __restrict__ fent, uint16_t* __restrict__ fkey) {
+                                                         uint32_t* __restrict__ gse, uint32_t* __restrict__ fent, uint16_t* __restrict__ fkey) {
   __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
   __shared__ uint32_t buf_ent[TABLE_TILE];
   __shared__ uint16_t buf_key[TABLE_TILE];
@@ -86,7 +97,7 @@ __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restri
   if (threadIdx.x < 128) {
     const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
     lstart[threadIdx.x] = excl;
-    gbase[threadIdx.x] = v ? atomicAdd(&gcursor[threadIdx.x], v) : 0;
+    gbase[threadIdx.x] = v ? table_claim(gcursor, gse, threadIdx.x, v) : 0;
     h[threadIdx.x] = excl;
   }
   __syncthreads();
@@ -116,7 +127,7 @@ __global__ void __launch_bounds__(1024) k_table_scatter(const uint32_t* __restri
 template <class Fr, int C>
 __global__ void __launch_bounds__(1024) k_table_scatter_static(const uint32_t* __restrict__ scalars, size_t n, int mont, AddConst K,
                                                                 int gbits, uint32_t W, uint32_t tile_scalars, uint32_t table_n,
-                                                                uint32_t first, uint32_t* __restrict__ gcursor,
+                                                                uint32_t first, uint32_t* __restrict__ gcursor, uint32_t* __restrict__ gse,
                                                                 uint32_t* __restrict__ fent, uint16_t* __restrict__ fkey) {
   constexpr int D = msm_table_digits(Fr::Params::BITS, C);
   __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
@@ -148,7 +159,7 @@ __global__ void __launch_bounds__(1024) k_table_scatter_static(const uint32_t* _
   if (threadIdx.x < 128) {
     const uint32_t excl = incl - v + (threadIdx.x >= 64 ? wsum : 0);
     lstart[threadIdx.x] = excl;
-    gbase[threadIdx.x] = v ? atomicAdd(&gcursor[threadIdx.x], v) : 0;
+    gbase[threadIdx.x] = v ? table_claim(gcursor, gse, threadIdx.x, v) : 0;
   }
   __syncthreads();
   if (live) {
@@ -174,10 +185,10 @@ __global__ void __launch_bounds__(1024) k_table_scatter_static(const uint32_t* _
 
 // bucket counts of a group from its key list (k_hist's counterpart); grid (chunks, W)
 static __global__ void __launch_bounds__(1024) k_hist_table(const uint16_t* __restrict__ fkey, const uint32_t* __restrict__ gstart,
-                                                            uint32_t nb, uint32_t* __restrict__ cnt) {
+                                                            const uint32_t* __restrict__ gend, uint32_t nb, uint32_t* __restrict__ cnt) {
   extern __shared__ uint32_t lh[];
   const uint32_t w = blockIdx.y;
-  const uint32_t start = gstart[w], end = gstart[w + 1];
+  const uint32_t start = gstart[w], end = gend[w];
   if (start == end) return;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
   __syncthreads();
@@ -220,11 +231,11 @@ static __global__ void __launch_bounds__(1024) k_hist_table(const uint16_t* __re
 
 // single-level finish for groups of fewer than 512 buckets (small tables): k_scatter's counterpart; grid (chunks, W)
 static __global__ void __launch_bounds__(1024) k_scatter_table(const uint32_t* __restrict__ fent, const uint16_t* __restrict__ fkey,
-                                                               const uint32_t* __restrict__ gstart, uint32_t nb,
-                                                               uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+                                                               const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gend,
+                                                               uint32_t nb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t lh[];
   const uint32_t w = blockIdx.y;
-  const uint32_t start = gstart[w], end = gstart[w + 1];
+  const uint32_t start = gstart[w], end = gend[w];
   if (start == end) return;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
   __syncthreads();
@@ -244,14 +255,14 @@ static __global__ void __launch_bounds__(1024) k_scatter_table(const uint32_t* _
 // k_scatter_hi's counterpart: tiles of a group's (entry, key) list split over the group's partitions of 256 buckets;
 // grid (tile slots, W), tiles taken grid-stride so that a group holding most entries is still covered
 static __global__ void __launch_bounds__(SORT_WG) k_scatter_hi_table(const uint32_t* __restrict__ fent, const uint16_t* __restrict__ fkey,
-                                                                  const uint32_t* __restrict__ gstart, uint32_t nhi,
-                                                                  uint32_t* __restrict__ cursor1, uint32_t* __restrict__ mid_ent,
+                                                                  const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gend,
+                                                                  uint32_t nhi, uint32_t* __restrict__ cursor1, uint32_t* __restrict__ mid_ent,
                                                                   uint8_t* __restrict__ mid_lo) {
   __shared__ uint32_t h[128], lstart[128], gbase[128], wsum;
   __shared__ uint32_t buf_ent[SORT_TILE1T];
   __shared__ uint8_t buf_lo[SORT_TILE1T], buf_bin[SORT_TILE1T];
   const uint32_t w = blockIdx.y;
-  const uint32_t start = gstart[w], end = gstart[w + 1];
+  const uint32_t start = gstart[w], end = gend[w];
   // Tiles start on multiples of SORT_PER entries (the first one below `start`, its leading entries masked), so that a lane
   // takes consecutive entries, eight at a time with one 16-byte load of keys and two of entries: with one narrow load per entry the
   // kernel waited on load latency, not bandwidth.  Which lane ranks which entry does not matter to a counting sort.
